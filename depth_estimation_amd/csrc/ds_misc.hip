@@ -1,0 +1,420 @@
+// ds_misc.hip -- plane sweep / cost volume / soft-argmin depth, edge-aware smoothness, depth metrics.
+//
+// Reference: synthesis.synthesize_from_depths (synthesis.py:57-80), metrics.cost_volumes (metrics.py:5-18),
+// synthesis.depth_from_costs (synthesis.py:119-138), metrics.regularization_term (metrics.py:75-97),
+// metrics.rmse/rmsle/abs_rel/sq_rel (metrics.py:100-153).
+#include "ds_common.h"
+#include "depthsynth.h"
+
+using namespace ds;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxPlanes = 128;
+
+struct Planes { float d[kMaxPlanes]; };  // fp32 plane depths (torch.ones(h,w)*depth is fp32, synthesis.py:69)
+
+inline int pix_blocks(int HW) { return (HW + kThreads - 1) / kThreads; }
+
+// ---------------------------------------------------------------------------------------------------
+// a4: D constant-depth warps of one source, materialised (D,C,H,W)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void plane_warp_kernel(const float* __restrict__ K, const float* __restrict__ Kinv,
+                                                              const float* __restrict__ pose, Planes planes,
+                                                              const float* __restrict__ src, int C, int Hs, int Ws, int H,
+                                                              int W, float* __restrict__ out) {
+    const int k = blockIdx.y;
+    const int p = blockIdx.x * kThreads + threadIdx.x;
+    if (p >= H * W) return;
+    Cam cam;
+    load_cam(cam, K, Kinv, pose);
+    const int y = p / W, x = p - y * W;
+    Proj pr;
+    project_pixel(cam, (float)x, (float)y, planes.d[k], pr);
+    Samp s;
+    sample_setup(pr.u, pr.v, Hs, Ws, s);
+    Corners co;
+    corner_offsets(s, Hs, Ws, co);
+    float* op = out + (size_t)k * C * H * W + p;
+    for (int c = 0; c < C; ++c) {
+        float nw, ne, sw, se;
+        gather4(src + (size_t)c * Hs * Ws, co, nw, ne, sw, se);
+        op[(size_t)c * H * W] = bilinear(nw, ne, sw, se, s);
+    }
+}
+
+// a5: cost (D,H,W) = mean_c |t - s|, channel sum in order then a correctly rounded /C
+__global__ __launch_bounds__(kThreads) void cost_volume_kernel(const float* __restrict__ target,
+                                                               const float* __restrict__ synth, int C, int HW,
+                                                               float* __restrict__ cost) {
+    const int k = blockIdx.y;
+    const int p = blockIdx.x * kThreads + threadIdx.x;
+    if (p >= HW) return;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+        float a = fabsf(target[(size_t)c * HW + p] - synth[((size_t)k * C + c) * HW + p]);
+        acc = (c == 0) ? a : acc + a;
+    }
+    cost[(size_t)k * HW + p] = (C == 3) ? div3(acc) : acc / (float)C;
+}
+
+__device__ __forceinline__ float index_to_depth(float m, int D, int sid) {
+    const float ln2 = 0.693147180559945f;  // torch.log(torch.tensor(2.0))
+    return sid ? (expf((m + 1.0f) * ln2 / (float)D) - 1.0f) : (m / (float)D + 1.0f / (float)D);
+}
+
+// a6: two passes over the D costs of a pixel (softmin = softmax of the negated, max-shifted values)
+__global__ __launch_bounds__(kThreads) void depth_from_costs_kernel(const float* __restrict__ cost, int D, int HW, int sid,
+                                                                    float* __restrict__ depth) {
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * kThreads + threadIdx.x;
+    if (p >= HW) return;
+    const float* c = cost + (size_t)n * D * HW + p;
+    float mn = INFINITY;
+    for (int k = 0; k < D; ++k) {
+        float e = expf(c[(size_t)k * HW]);
+        mn = fminf(mn, e * e - 1.0f);
+    }
+    float den = 0.f, num = 0.f;
+    for (int k = 0; k < D; ++k) {
+        float e = expf(c[(size_t)k * HW]);
+        float w = expf(mn - (e * e - 1.0f));
+        den += w;
+        num = fmaf(w, (float)k, num);
+    }
+    depth[(size_t)n * HW + p] = index_to_depth(num / den, D, sid);
+}
+
+// fused a4+a5+a6: one thread per (source, pixel), online softmin over the planes; nothing materialised
+__global__ __launch_bounds__(kThreads) void plane_sweep_depth_kernel(const float* __restrict__ K,
+                                                                     const float* __restrict__ Kinv,
+                                                                     const float* __restrict__ pose, Planes planes, int D,
+                                                                     const float* __restrict__ src,
+                                                                     const float* __restrict__ target, int C, int Hs, int Ws,
+                                                                     int H, int W, int sid, float* __restrict__ depth) {
+    const int n = blockIdx.y;
+    const int HW = H * W;
+    const int p = blockIdx.x * kThreads + threadIdx.x;
+    if (p >= HW) return;
+    Cam cam;
+    load_cam(cam, K, Kinv, pose + 12 * n);
+    const float* sp = src + (size_t)n * C * Hs * Ws;
+    const int y = p / W, x = p - y * W;
+    float run_min = INFINITY, den = 0.f, num = 0.f;
+    for (int k = 0; k < D; ++k) {
+        Proj pr;
+        project_pixel(cam, (float)x, (float)y, planes.d[k], pr);
+        Samp s;
+        sample_setup(pr.u, pr.v, Hs, Ws, s);
+        Corners co;
+        corner_offsets(s, Hs, Ws, co);
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float nw, ne, sw, se;
+            gather4(sp + (size_t)c * Hs * Ws, co, nw, ne, sw, se);
+            float a = fabsf(target[(size_t)c * HW + p] - bilinear(nw, ne, sw, se, s));
+            acc = (c == 0) ? a : acc + a;
+        }
+        const float cst = (C == 3) ? div3(acc) : acc / (float)C;
+        const float e = expf(cst);
+        const float v = e * e - 1.0f;
+        if (v < run_min) {  // new minimum: rescale what has been accumulated so far
+            const float r = expf(v - run_min);  // exp(-inf) = 0 on the first plane
+            den *= r;
+            num *= r;
+            run_min = v;
+        }
+        const float w = expf(run_min - v);
+        den += w;
+        num = fmaf(w, (float)k, num);
+    }
+    depth[(size_t)n * HW + p] = index_to_depth(num / den, D, sid);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a10: edge-aware smoothness
+// ---------------------------------------------------------------------------------------------------
+// torch.gradient with unit spacing along a line of length L and element stride `st`
+__device__ __forceinline__ float grad1d(const float* __restrict__ f, int i, int L, int st) {
+    if (L == 1) return 0.f;
+    if (i == 0) return f[st] - f[0];
+    if (i == L - 1) return f[(L - 1) * st] - f[(L - 2) * st];
+    return (f[(i + 1) * st] - f[(i - 1) * st]) * 0.5f;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* lds) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += lds[w];
+    return r;  // valid on thread 0
+}
+
+__global__ __launch_bounds__(kThreads) void smooth_fwd_kernel(const float* __restrict__ depths,
+                                                              const float* __restrict__ targets, int C, int H, int W,
+                                                              float* __restrict__ partials) {
+    __shared__ float lds[kThreads / 64];
+    const int n = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * kThreads + threadIdx.x;
+    float term = 0.f;
+    if (p < HW) {
+        const int y = p / W, x = p - y * W;
+        const float* D = depths + (size_t)n * HW;
+        const float adx = fabsf(grad1d(D + y * W, x, W, 1)), ady = fabsf(grad1d(D + x, y, H, W));
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float* I = targets + ((size_t)n * C + c) * HW;
+            const float ex = expf(fabsf(grad1d(I + y * W, x, W, 1)));
+            const float ey = expf(fabsf(grad1d(I + x, y, H, W)));
+            const float t = adx / ex + ady / ey;
+            acc = (c == 0) ? t : acc + t;
+        }
+        term = acc / (float)C;
+    }
+    const float s = block_sum(term, lds);
+    if (threadIdx.x == 0) partials[(size_t)n * gridDim.x + blockIdx.x] = s;
+}
+
+__global__ void sum_finalize_kernel(const float* __restrict__ partials, int n, double scale, float* __restrict__ out) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) a += (double)partials[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (threadIdx.x == 0) out[0] = (float)(a * scale);
+}
+
+// q = d(term)/d(ddx) at pixel (y,x): upstream * sign(ddx) * sum_c exp(-|dI_c|) / C   (x direction; y alike)
+__device__ __forceinline__ void smooth_q(const float* __restrict__ D, const float* __restrict__ T, int C, int H, int W, int y,
+                                         int x, float g, float& qx, float& qy) {
+    const int HW = H * W;
+    const float ddx = grad1d(D + y * W, x, W, 1), ddy = grad1d(D + x, y, H, W);
+    float wx = 0.f, wy = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float* I = T + (size_t)c * HW;
+        wx += 1.0f / expf(fabsf(grad1d(I + y * W, x, W, 1)));
+        wy += 1.0f / expf(fabsf(grad1d(I + x, y, H, W)));
+    }
+    qx = g * wx * (ddx > 0.f ? 1.0f : (ddx < 0.f ? -1.0f : 0.0f));
+    qy = g * wy * (ddy > 0.f ? 1.0f : (ddy < 0.f ? -1.0f : 0.0f));
+}
+
+// adjoint of torch.gradient along one line: contribution of q[j-1], q[j], q[j+1] to element j
+__device__ __forceinline__ float grad1d_adjoint(float qm, float q0, float qp, int j, int L) {
+    if (L == 1) return 0.f;
+    float g = 0.f;
+    if (j >= 1) g += (j - 1 == 0 ? 1.0f : 0.5f) * qm;
+    if (j <= L - 2) g -= (j + 1 == L - 1 ? 1.0f : 0.5f) * qp;
+    if (j == 0) g -= q0;
+    if (j == L - 1) g += q0;
+    return g;
+}
+
+__global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(const float* __restrict__ depths,
+                                                              const float* __restrict__ targets,
+                                                              const float* __restrict__ g_value, int N, int C, int H, int W,
+                                                              float* __restrict__ g_depths) {
+    const int n = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * kThreads + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const float* D = depths + (size_t)n * HW;
+    const float* T = targets + (size_t)n * C * HW;
+    const float g = g_value[0] / ((float)N * (float)HW) / (float)C;
+    float qx0, qy0, qxm = 0.f, qxp = 0.f, qym = 0.f, qyp = 0.f, dummy;
+    smooth_q(D, T, C, H, W, y, x, g, qx0, qy0);
+    if (x >= 1) smooth_q(D, T, C, H, W, y, x - 1, g, qxm, dummy);
+    if (x <= W - 2) smooth_q(D, T, C, H, W, y, x + 1, g, qxp, dummy);
+    if (y >= 1) smooth_q(D, T, C, H, W, y - 1, x, g, dummy, qym);
+    if (y <= H - 2) smooth_q(D, T, C, H, W, y + 1, x, g, dummy, qyp);
+    g_depths[(size_t)n * HW + p] = grad1d_adjoint(qxm, qx0, qxp, x, W) + grad1d_adjoint(qym, qy0, qyp, y, H);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a11-a15: all depth metrics in one pass
+// ---------------------------------------------------------------------------------------------------
+constexpr int kMetPix = 8;  // pixels per thread
+
+__global__ __launch_bounds__(kThreads) void metrics_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                           int HW, float* __restrict__ partials) {
+    __shared__ float lds[8][kThreads / 64];
+    const int b = blockIdx.y;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float* P = pred + (size_t)b * HW;
+    const float* G = gt + (size_t)b * HW;
+#pragma unroll
+    for (int it = 0; it < kMetPix; ++it) {
+        const int i = (blockIdx.x * kMetPix + it) * kThreads + threadIdx.x;
+        if (i < HW) {
+            const float p = P[i], g = G[i];
+            if (g > 0.0f) {
+                const float df = p - g, sq = df * df;
+                const float lg = logf(p + 1e-6f) - logf(g + 1e-6f);
+                a[0] += sq;
+                a[1] += lg * lg;
+                a[2] += fabsf(df) / g;
+                a[3] += sq / g;
+                const float r = fmaxf(p / g, g / p);
+                a[4] += r < 1.25f ? 1.f : 0.f;
+                a[5] += r < 1.5625f ? 1.f : 0.f;
+                a[6] += r < 1.953125f ? 1.f : 0.f;
+                a[7] += 1.f;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a[k] = wave_sum(a[k]);
+        if (lane == 0) lds[k][wave] = a[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        float s = 0.f;
+        for (int w = 0; w < kThreads / 64; ++w) s += lds[threadIdx.x][w];
+        partials[((size_t)b * gridDim.x + blockIdx.x) * 8 + threadIdx.x] = s;
+    }
+}
+
+// partials (B, nblk, 8) -> out (8): per-image finalisation then mean over B (metrics.py:111,125,139,153)
+__global__ void metrics_finalize_kernel(const float* __restrict__ partials, int B, int nblk, double inv_hw,
+                                        float* __restrict__ out) {
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < B; b += 64) {
+        double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < nblk; ++j)
+            for (int k = 0; k < 8; ++k) s[k] += (double)partials[((size_t)b * nblk + j) * 8 + k];
+        acc[0] += sqrt(s[0] * inv_hw);
+        acc[1] += sqrt(s[1] * inv_hw);
+        for (int k = 2; k < 7; ++k) acc[k] += s[k] * inv_hw;
+        acc[7] += s[7];
+    }
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+    }
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 7; ++k) out[k] = (float)(acc[k] / (double)B);
+        out[7] = (float)acc[7];
+    }
+}
+
+inline bool bad_img(int N, int C, int H, int W) {
+    return N <= 0 || C <= 0 || H <= 0 || W <= 0 || N > 65535 || (long long)H * W > (1ll << 30);
+}
+
+inline int metric_blocks(int HW) { return (HW + kThreads * kMetPix - 1) / (kThreads * kMetPix); }
+
+inline bool fill_planes(Planes& pl, const double* depths_host, int D) {
+    if (!depths_host || D <= 0 || D > kMaxPlanes) return false;
+    for (int k = 0; k < D; ++k) pl.d[k] = (float)depths_host[k];
+    for (int k = D; k < kMaxPlanes; ++k) pl.d[k] = 0.f;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ds_version(void) { return 100; }
+
+const char* ds_error_string(int code) {
+    switch (code) {
+        case DS_OK: return "ok";
+        case DS_ERR_INVALID_ARG: return "depthsynth: invalid argument (null pointer or dimension out of range)";
+        case DS_ERR_UNSUPPORTED: return "depthsynth: unsupported configuration (e.g. more than DS_MAX_SOURCES sources)";
+        case DS_ERR_WORKSPACE: return "depthsynth: workspace missing or too small";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "depthsynth: unknown error";
+    }
+}
+
+int ds_synthesize_from_depths(const float* K, const float* Kinv, const float* pose, const double* depths_host, int D,
+                              const float* src, int C, int Hs, int Ws, int H, int W, float* out, void* stream) {
+    Planes pl;
+    if (!K || !Kinv || !pose || !src || !out || bad_img(D, C, H, W) || Hs < 2 || Ws < 2 || !fill_planes(pl, depths_host, D))
+        return DS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(plane_warp_kernel, dim3(pix_blocks(H * W), D), dim3(kThreads), 0, (hipStream_t)stream, K, Kinv, pose, pl,
+                       src, C, Hs, Ws, H, W, out);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_cost_volume(const float* target, const float* synth, int D, int C, int H, int W, float* cost, void* stream) {
+    if (!target || !synth || !cost || bad_img(D, C, H, W)) return DS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(cost_volume_kernel, dim3(pix_blocks(H * W), D), dim3(kThreads), 0, (hipStream_t)stream, target, synth, C,
+                       H * W, cost);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_depth_from_costs(const float* cost, int N, int D, int H, int W, int sid, float* depth, void* stream) {
+    if (!cost || !depth || bad_img(N, D, H, W)) return DS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(depth_from_costs_kernel, dim3(pix_blocks(H * W), N), dim3(kThreads), 0, (hipStream_t)stream, cost, D,
+                       H * W, sid, depth);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_plane_sweep_depth(const float* K, const float* Kinv, const float* pose, const double* depths_host, int D,
+                         const float* src, const float* target_small, int NS, int C, int Hs, int Ws, int H, int W,
+                         int sid, float* depth, void* stream) {
+    Planes pl;
+    if (!K || !Kinv || !pose || !src || !target_small || !depth || bad_img(NS, C, H, W) || Hs < 2 || Ws < 2 ||
+        !fill_planes(pl, depths_host, D))
+        return DS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(plane_sweep_depth_kernel, dim3(pix_blocks(H * W), NS), dim3(kThreads), 0, (hipStream_t)stream, K, Kinv,
+                       pose, pl, D, src, target_small, C, Hs, Ws, H, W, sid, depth);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+size_t ds_smooth_workspace_bytes(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)N * pix_blocks(H * W) * sizeof(float);
+}
+
+int ds_smooth_fwd(const float* depths, const float* targets, int N, int C, int H, int W, float* value, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+    if (!depths || !targets || !value || bad_img(N, C, H, W)) return DS_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < ds_smooth_workspace_bytes(N, H, W)) return DS_ERR_WORKSPACE;
+    const int nb = pix_blocks(H * W);
+    hipLaunchKernelGGL(smooth_fwd_kernel, dim3(nb, N), dim3(kThreads), 0, (hipStream_t)stream, depths, targets, C, H, W,
+                       (float*)workspace);
+    DS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, nb * N,
+                       1.0 / ((double)N * H * W), value);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_smooth_bwd(const float* depths, const float* targets, const float* g_value, int N, int C, int H, int W,
+                  float* g_depths, void* stream) {
+    if (!depths || !targets || !g_value || !g_depths || bad_img(N, C, H, W)) return DS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(smooth_bwd_kernel, dim3(pix_blocks(H * W), N), dim3(kThreads), 0, (hipStream_t)stream, depths, targets,
+                       g_value, N, C, H, W, g_depths);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+size_t ds_metrics_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * metric_blocks(H * W) * 8 * sizeof(float);
+}
+
+int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, float* out, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (!pred || !gt || !out || bad_img(B, 1, H, W)) return DS_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < ds_metrics_workspace_bytes(B, H, W)) return DS_ERR_WORKSPACE;
+    const int nb = metric_blocks(H * W);
+    hipLaunchKernelGGL(metrics_kernel, dim3(nb, B), dim3(kThreads), 0, (hipStream_t)stream, pred, gt, H * W, (float*)workspace);
+    DS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, B, nb,
+                       1.0 / ((double)H * W), out);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,730 @@
+// ds_photo.hip -- SSIM + L1 photometric error, per-pixel min over sources, soft auto-mask ratio,
+// forward and backward.
+//
+// Reference: metrics.reprojection_error (metrics.py:21-51), metrics.reprojection_loss
+// (metrics.py:54-72), loss assembly train.py:80-92, and their autograd.
+//
+// Kernel shape ("rolling wave"): one 64-lane wavefront owns a band of columns (one column per lane) and
+// walks down a chunk of rows.  Each lane keeps the last three rows of every plane in registers; the
+// left/right neighbours of the 3x3 window come from the adjacent lanes through DPP wave shifts that fold
+// into the adds, so the stencil needs no LDS and every global access is a 256-B coalesced row segment.
+// Halo columns/rows are re-loaded (reflect-indexed, which is exactly functional.pad(mode="reflect")).
+//
+// The 9-tap sums are sequential, row-major, separately rounded, then divided by 9 with a correctly
+// rounded divide: bit-identical to torch's avg_pool2d.  VALU-heavy by necessity:
+// 5 window sums x 9 taps per (pixel, channel, image pair) cannot be shared between windows without
+// changing the rounding order.
+#include "ds_common.h"
+#include "depthsynth.h"
+
+using namespace ds;
+
+namespace {
+
+constexpr int kWaves = 4;  // wavefronts per block (independent of each other)
+
+// sequential 3x3 window sum over three rolling rows; T,M,B = slots of rows r-1, r, r+1
+template <int T, int M, int B>
+__device__ __forceinline__ float win9(const float (&a)[3]) {
+    float t = a[T], m = a[M], b = a[B];
+    float acc = lane_left(t) + t;
+    tie(acc, t);
+    acc = acc + lane_right(t);
+    tie(acc, m);
+    acc = acc + lane_left(m);
+    acc = acc + m;
+    tie(acc, m);
+    acc = acc + lane_right(m);
+    tie(acc, b);
+    acc = acc + lane_left(b);
+    acc = acc + b;
+    tie(acc, b);
+    acc = acc + lane_right(b);
+    return acc;
+}
+
+// same sum over the products a*b of two rolling planes (x*x, y*y, x*y of metrics.py:41-43): the three
+// per-row products are formed once per lane, their neighbours again come through DPP
+template <int T, int M, int B>
+__device__ __forceinline__ float win9p(const float (&a)[3], const float (&b)[3]) {
+    const float p[3] = {a[T] * b[T], a[M] * b[M], a[B] * b[B]};
+    return win9<0, 1, 2>(p);
+}
+
+struct BandGeom {
+    int b, y0, yend, col, cl, lane;
+    bool active;
+};
+
+// wave -> (image b, row chunk, column band).  USEFUL = 64 - 2*halo columns per band.
+template <int HALO>
+__device__ __forceinline__ BandGeom band_geom(int B, int H, int W, int nbx, int nby, int RB) {
+    BandGeom g;
+    const int wave = threadIdx.x >> 6;
+    g.lane = threadIdx.x & 63;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x) * kWaves + wave;
+    g.active = wg < B * nby * nbx;
+    const int bx = wg % nbx, t = wg / nbx, by = t % nby;
+    g.b = t / nby;
+    g.y0 = by * RB;
+    g.yend = min(g.y0 + RB, H);
+    g.col = bx * (64 - 2 * HALO) - HALO + g.lane;
+    g.cl = reflect_idx(g.col, W);
+    return g;
+}
+
+// =====================================================================================================
+// forward: G pred groups of 3 channels each against one target.  Groups 0..S-1 are the warped images
+// (min -> out, argmin/pass bits -> aux); with IDT, groups S..2S-1 are the un-warped sources (min -> idt).
+// =====================================================================================================
+struct PhotoFwdParams {
+    const float* preds;     // (B, S_total, 3, H, W); already offset to the first source of this launch
+    const float* src;       // IDT only: (B, S, 3, H, W)
+    const float* target;
+    long long pred_stride_b, tgt_stride_b;
+    int B, H, W, nbx, nby, RB;
+    int s_offset;           // index of this launch's first source (chunked S / per-source targets)
+    float* out;             // (B,H,W)
+    float* idt;             // (B,H,W), IDT only
+    uint8_t* aux;           // (B,H,W) or NULL
+    float* wave_partials;   // (nwaves, 2), IDT only
+};
+
+template <int S, bool IDT>
+struct FwdState {
+    static constexpr int G = IDT ? 2 * S : S;
+    float X[G][3][3];  // [group][channel][slot]; products are re-formed per window (registers > 6 % VALU)
+    float Y[3][3];
+};
+
+template <int S, bool IDT, int SLOT>
+__device__ __forceinline__ void fwd_place(FwdState<S, IDT>& st, const float (&nx)[FwdState<S, IDT>::G][3],
+                                          const float (&ny)[3]) {
+    constexpr int G = FwdState<S, IDT>::G;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        st.Y[c][SLOT] = ny[c];
+#pragma unroll
+        for (int g = 0; g < G; ++g) st.X[g][c][SLOT] = nx[g][c];
+    }
+}
+
+// photometric error of the window centred on row MID for every group; E[g] = ((e0+e1)+e2)/3
+template <int S, bool IDT, int T, int M, int Bt>
+__device__ __forceinline__ void fwd_window(FwdState<S, IDT>& st, float (&E)[FwdState<S, IDT>::G],
+                                           unsigned (&pass)[FwdState<S, IDT>::G]) {
+    constexpr int G = FwdState<S, IDT>::G;
+#pragma unroll
+    for (int g = 0; g < G; ++g) pass[g] = 0u;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            opaque(st.Y[c][k]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) opaque(st.X[g][c][k]);
+        }
+        TgtStats ts;
+        target_stats(win9<T, M, Bt>(st.Y[c]), win9p<T, M, Bt>(st.Y[c], st.Y[c]), ts);
+        const float yc = st.Y[c][M];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            SsimOut so;
+            ssim_from_sums(win9<T, M, Bt>(st.X[g][c]), win9p<T, M, Bt>(st.X[g][c], st.X[g][c]),
+                           win9p<T, M, Bt>(st.X[g][c], st.Y[c]), ts, so);
+            const float e = 0.85f * clamp01(so.v) + 0.15f * fabsf(yc - st.X[g][c][M]);
+            E[g] = (c == 0) ? e : E[g] + e;
+            pass[g] |= (so.v >= 0.0f && so.v <= 1.0f) ? (1u << c) : 0u;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) E[g] = div3(E[g]);
+}
+
+template <int S, bool IDT>
+__global__ __launch_bounds__(64 * kWaves) void photo_fwd_kernel(PhotoFwdParams P) {
+    constexpr int G = FwdState<S, IDT>::G;
+    const BandGeom g = band_geom<1>(P.B, P.H, P.W, P.nbx, P.nby, P.RB);
+    if (!g.active) return;
+    const int H = P.H, W = P.W;
+    const size_t HW = (size_t)H * W;
+    const float* tp = P.target + (size_t)g.b * P.tgt_stride_b + g.cl;
+    const float* pp = P.preds + (size_t)g.b * P.pred_stride_b + g.cl;
+    const float* sp = IDT ? P.src + (size_t)g.b * (S * 3 * HW) + g.cl : nullptr;
+    const bool lane_out = g.lane >= 1 && g.lane <= 62 && g.col < W;
+
+    FwdState<S, IDT> st;
+    float nx[G][3], ny[3];
+    auto load_row = [&](int r) {
+        const size_t ro = (size_t)reflect_idx(r, H) * W;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ny[c] = tp[c * HW + ro];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                nx[s][c] = pp[(s * 3 + c) * HW + ro];
+                if (IDT) nx[S + s][c] = sp[(s * 3 + c) * HW + ro];
+            }
+        }
+    };
+    float sum_ratio = 0.f, sum_out = 0.f;
+    auto emit = [&](int y, const float (&E)[G], const unsigned (&pass)[G]) {
+        float best = E[0];
+        int bi = 0;
+#pragma unroll
+        for (int s = 1; s < S; ++s)
+            if (E[s] < best) { best = E[s]; bi = s; }
+        unsigned pb = pass[0];
+#pragma unroll
+        for (int s = 1; s < S; ++s) pb = (bi == s) ? pass[s] : pb;
+        const size_t o = (size_t)g.b * HW + (size_t)y * W + g.col;
+        if (lane_out) {
+            unsigned a = (unsigned)(bi + P.s_offset) | (pb << 5);
+            bool keep = true;
+            if (P.s_offset > 0) keep = best < P.out[o];  // later chunk: strictly smaller wins (first index on ties)
+            if (keep) {
+                P.out[o] = best;
+                if (P.aux) P.aux[o] = (uint8_t)a;
+            }
+            if (IDT) {
+                float bid = E[S];
+#pragma unroll
+                for (int s = 1; s < S; ++s) bid = fminf(bid, E[S + s]);
+                P.idt[o] = bid;
+                sum_ratio += best / expf(bid + 1e-6f);  // train.py:88
+                sum_out += best;                        // train.py:92
+            }
+        }
+    };
+
+    // prologue: rows y0-1, y0 into slots 0,1; steady state handles row r in slot (r-(y0-1))%3
+    load_row(g.y0 - 1);
+    fwd_place<S, IDT, 0>(st, nx, ny);
+    load_row(g.y0);
+    fwd_place<S, IDT, 1>(st, nx, ny);
+    load_row(g.y0 + 1);
+    float E[G];
+    unsigned pass[G];
+    for (int y = g.y0; y < g.yend; y += 3) {
+        // output row y: rows (y-1,y,y+1) in slots (0,1,2)
+        fwd_place<S, IDT, 2>(st, nx, ny);
+        if (y + 1 < g.yend) load_row(y + 2);
+        fwd_window<S, IDT, 0, 1, 2>(st, E, pass);
+        emit(y, E, pass);
+        if (y + 1 >= g.yend) break;
+        fwd_place<S, IDT, 0>(st, nx, ny);
+        if (y + 2 < g.yend) load_row(y + 3);
+        fwd_window<S, IDT, 1, 2, 0>(st, E, pass);
+        emit(y + 1, E, pass);
+        if (y + 2 >= g.yend) break;
+        fwd_place<S, IDT, 1>(st, nx, ny);
+        if (y + 3 < g.yend) load_row(y + 4);
+        fwd_window<S, IDT, 2, 0, 1>(st, E, pass);
+        emit(y + 2, E, pass);
+    }
+    if (IDT) {
+        sum_ratio = wave_sum(sum_ratio);
+        sum_out = wave_sum(sum_out);
+        if (g.lane == 0) {
+            const int wg = xcd_remap(blockIdx.x, gridDim.x) * kWaves + (threadIdx.x >> 6);
+            P.wave_partials[2 * wg + 0] = sum_ratio;
+            P.wave_partials[2 * wg + 1] = sum_out;
+        }
+    }
+}
+
+// per-image sums of the wave partials, fixed order, double accumulation -> means (B,2)
+__global__ void loss_finalize_kernel(const float* __restrict__ wave_partials, int waves_per_image, double inv_hw,
+                                     float* __restrict__ sums) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = lane; i < waves_per_image; i += 64) {
+        a0 += (double)wave_partials[2 * ((size_t)b * waves_per_image + i) + 0];
+        a1 += (double)wave_partials[2 * ((size_t)b * waves_per_image + i) + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a0 += __shfl_xor(a0, o, 64);
+        a1 += __shfl_xor(a1, o, 64);
+    }
+    if (lane == 0) {
+        sums[2 * b + 0] = (float)(a0 * inv_hw);
+        sums[2 * b + 1] = (float)(a1 * inv_hw);
+    }
+}
+
+// =====================================================================================================
+// plain SSIM map of independent planes (metrics.reprojection_error), same rolling scheme
+// =====================================================================================================
+__global__ __launch_bounds__(64 * kWaves) void ssim_fwd_kernel(const float* __restrict__ preds,
+                                                               const float* __restrict__ targets, int nplanes, int H,
+                                                               int W, int nbx, int nby, int RB, float* __restrict__ out) {
+    const BandGeom g = band_geom<1>(nplanes, H, W, nbx, nby, RB);
+    if (!g.active) return;
+    const size_t HW = (size_t)H * W;
+    const float* xp = preds + (size_t)g.b * HW + g.cl;
+    const float* yp = targets + (size_t)g.b * HW + g.cl;
+    const bool lane_out = g.lane >= 1 && g.lane <= 62 && g.col < W;
+    float X[3], XX[3], XY[3], Y[3], YY[3];
+    auto place = [&](int slot, int r) {
+        const size_t ro = (size_t)reflect_idx(r, H) * W;
+        float x = xp[ro], y = yp[ro];
+        // slot is a compile-time constant at every call site after unrolling
+        X[slot] = x; Y[slot] = y; XX[slot] = x * x; YY[slot] = y * y; XY[slot] = x * y;
+    };
+    auto emit = [&](int y, float ax, float ay, float axx, float ayy, float axy) {
+        TgtStats ts;
+        target_stats(ay, ayy, ts);
+        SsimOut so;
+        ssim_from_sums(ax, axx, axy, ts, so);
+        if (lane_out) out[(size_t)g.b * HW + (size_t)y * W + g.col] = clamp01(so.v);
+    };
+    place(0, g.y0 - 1);
+    place(1, g.y0);
+    for (int y = g.y0; y < g.yend; y += 3) {
+        place(2, y + 1);
+        emit(y, win9<0, 1, 2>(X), win9<0, 1, 2>(Y), win9<0, 1, 2>(XX), win9<0, 1, 2>(YY), win9<0, 1, 2>(XY));
+        if (y + 1 >= g.yend) break;
+        place(0, y + 2);
+        emit(y + 1, win9<1, 2, 0>(X), win9<1, 2, 0>(Y), win9<1, 2, 0>(XX), win9<1, 2, 0>(YY), win9<1, 2, 0>(XY));
+        if (y + 2 >= g.yend) break;
+        place(1, y + 3);
+        emit(y + 2, win9<2, 0, 1>(X), win9<2, 0, 1>(Y), win9<2, 0, 1>(XX), win9<2, 0, 1>(YY), win9<2, 0, 1>(XY));
+    }
+}
+
+// =====================================================================================================
+// backward.  Window (q) -> tap coefficients: d loss / d x_tap = (A_q + Bq * x_tap + Cq * y_tap), already
+// divided by 9; a pixel sums them over the windows that contain it (reflect-pad adjoint = multiplicity 2
+// for the border windows seen from the second row/column).
+// =====================================================================================================
+struct Coef { float A, Bc, Cc; };
+
+// g_v = d loss / d v of this window & channel (0 when the clamp blocked it)
+__device__ __forceinline__ Coef ssim_coefs(const SsimOut& so, const TgtStats& ts, float g_v) {
+    const float rdd = 1.0f / so.dd;
+    const float g_n = -0.5f * g_v * rdd;
+    const float g_dd = -g_n * so.n * rdd;
+    const float mx2 = so.mx * so.mx;
+    const float a = fmaf(2.0f, so.mx * ts.my, kC1), bb = fmaf(2.0f, so.sxy, kC2);
+    const float cc = (mx2 + ts.my2) + kC1, ee = (so.sx + ts.sy_raw) + kC2;
+    const float g_a = g_n * bb, g_b = g_n * a, g_c = g_dd * ee, g_sx = g_dd * cc;
+    const float g_sxy = 2.0f * g_b;
+    // g_mx = 2 my g_a + 2 mx g_c - 2 mx g_sx - my g_sxy
+    const float g_mx = fmaf(2.0f * ts.my, g_a, 2.0f * so.mx * (g_c - g_sx)) - ts.my * g_sxy;
+    const float ninth = 1.0f / 9.0f;
+    Coef k;
+    k.A = g_mx * ninth;
+    k.Bc = 2.0f * g_sx * ninth;
+    k.Cc = g_sxy * ninth;
+    return k;
+}
+
+struct PhotoBwdParams {
+    const float* preds;     // (B, S_total, 3, H, W) offset to this launch's first source
+    const float* target;
+    long long pred_stride_b, tgt_stride_b;
+    const float* g_out;     // !FUSED: (B,H,W) upstream gradient of the min map
+    const float* idt;       // FUSED: (B,H,W)
+    const float* g_sums;    // FUSED: (B) upstream gradient of mean(out/exp(idt+1e-6))
+    const uint8_t* aux;     // (B,H,W)
+    int B, H, W, nbx, nby, RB, s_offset;
+    float inv_hw;
+    float* g_preds;         // (B, S_total, 3, H, W) offset like preds
+};
+
+template <int S>
+struct BwdState {
+    float X[S][3][3];
+    float Y[3][3];
+    float GW[3];            // per-pixel weight d loss / d out(p), by slot
+    int AM[3];              // aux byte, by slot
+    float ACC[3][S][3][3];  // [slot of output row][s][c][A,B,C]
+};
+
+template <int S, int SLOT>
+__device__ __forceinline__ void bwd_place(BwdState<S>& st, const float (&nx)[S][3], const float (&ny)[3], float gw, int am) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        st.Y[c][SLOT] = ny[c];
+#pragma unroll
+        for (int s = 0; s < S; ++s) st.X[s][c][SLOT] = nx[s][c];
+    }
+    st.GW[SLOT] = gw;
+    st.AM[SLOT] = am;
+}
+
+// coefficients of window row M (rows T,M,Bt present), spread horizontally, accumulated into the three
+// output rows it touches: Bt-slot row (initialised, weight wU), M-slot row (+=), T-slot row (+= weight wD).
+template <int S, int T, int M, int Bt>
+__device__ __forceinline__ void bwd_window(BwdState<S>& st, bool win_exists, int s_offset, float wL, float wR, float wU_next,
+                                           float wD_prev) {
+    const int am = st.AM[M] & 0x1f;
+    const int passbits = st.AM[M] >> 5;
+    const float ge = win_exists ? st.GW[M] * (1.0f / 3.0f) : 0.0f;  // d loss / d e_c of this window
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        TgtStats ts;
+        target_stats(win9<T, M, Bt>(st.Y[c]), win9p<T, M, Bt>(st.Y[c], st.Y[c]), ts);
+        const float gv_c = ((passbits >> c) & 1) ? 0.85f * ge : 0.0f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            SsimOut so;
+            ssim_from_sums(win9<T, M, Bt>(st.X[s][c]), win9p<T, M, Bt>(st.X[s][c], st.X[s][c]),
+                           win9p<T, M, Bt>(st.X[s][c], st.Y[c]), ts, so);
+            const float gv = (am == s + s_offset) ? gv_c : 0.0f;
+            const Coef k = ssim_coefs(so, ts, gv);
+            const float hA = fmaf(wL, lane_left(k.A), fmaf(wR, lane_right(k.A), k.A));
+            const float hB = fmaf(wL, lane_left(k.Bc), fmaf(wR, lane_right(k.Bc), k.Bc));
+            const float hC = fmaf(wL, lane_left(k.Cc), fmaf(wR, lane_right(k.Cc), k.Cc));
+            st.ACC[Bt][s][c][0] = wU_next * hA;
+            st.ACC[Bt][s][c][1] = wU_next * hB;
+            st.ACC[Bt][s][c][2] = wU_next * hC;
+            st.ACC[M][s][c][0] += hA;
+            st.ACC[M][s][c][1] += hB;
+            st.ACC[M][s][c][2] += hC;
+            st.ACC[T][s][c][0] = fmaf(wD_prev, hA, st.ACC[T][s][c][0]);
+            st.ACC[T][s][c][1] = fmaf(wD_prev, hB, st.ACC[T][s][c][1]);
+            st.ACC[T][s][c][2] = fmaf(wD_prev, hC, st.ACC[T][s][c][2]);
+        }
+    }
+}
+
+template <int S, bool FUSED>
+__global__ __launch_bounds__(64 * kWaves) void photo_bwd_kernel(PhotoBwdParams P) {
+    const BandGeom g = band_geom<2>(P.B, P.H, P.W, P.nbx, P.nby, P.RB);
+    if (!g.active) return;
+    const int H = P.H, W = P.W;
+    const size_t HW = (size_t)H * W;
+    const float* tp = P.target + (size_t)g.b * P.tgt_stride_b + g.cl;
+    const float* pp = P.preds + (size_t)g.b * P.pred_stride_b + g.cl;
+    float* gp = P.g_preds + (size_t)g.b * P.pred_stride_b + g.col;
+    const float* wp = (FUSED ? P.idt : P.g_out) + (size_t)g.b * HW + g.cl;
+    const uint8_t* ap = P.aux + (size_t)g.b * HW + g.cl;
+    const float gscale = FUSED ? P.g_sums[g.b] * P.inv_hw : 1.0f;
+    const bool col_exists = g.col >= 0 && g.col < W;
+    const bool lane_out = g.lane >= 2 && g.lane <= 61 && g.col < W;
+    const float wL = g.col == 1 ? 2.0f : 1.0f, wR = g.col == W - 2 ? 2.0f : 1.0f;
+
+    BwdState<S> st;
+    float nx[S][3], ny[3], ngw;
+    int nam;
+    auto load_row = [&](int r) {
+        const size_t ro = (size_t)reflect_idx(r, H) * W;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ny[c] = tp[c * HW + ro];
+#pragma unroll
+            for (int s = 0; s < S; ++s) nx[s][c] = pp[(s * 3 + c) * HW + ro];
+        }
+        const float w = wp[ro];
+        ngw = FUSED ? gscale / expf(w + 1e-6f) : w;
+        nam = ap[ro];
+    };
+    // emit output row t held in slot TS (values X/Y/GW/AM of row t live in the same slot)
+    auto emit = [&](int t, int /*unused*/, const float (&acc)[S][3][3], const float (&X)[S][3], const float (&Y)[3], float gw,
+                    int am) {
+        if (!lane_out) return;
+        const float ge = gw * (1.0f / 3.0f);
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float gg = fmaf(Y[c], acc[s][c][2], fmaf(X[s][c], acc[s][c][1], acc[s][c][0]));
+                const float diff = Y[c] - X[s][c];
+                const float sgn = diff > 0.f ? -1.0f : (diff < 0.f ? 1.0f : 0.0f);
+                if ((am & 0x1f) == s + P.s_offset) gg = fmaf(0.15f * ge, sgn, gg);
+                gp[(s * 3 + c) * HW + (size_t)t * W] = gg;
+            }
+    };
+    auto row_of = [&](int slot, float (&X)[S][3], float (&Y)[3]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            Y[c] = st.Y[c][slot];
+#pragma unroll
+            for (int s = 0; s < S; ++s) X[s][c] = st.X[s][c][slot];
+        }
+    };
+    auto wU = [&](int t) { return t == 1 ? 2.0f : 1.0f; };
+    auto wD = [&](int t) { return t == H - 2 ? 2.0f : 1.0f; };
+
+    // rows y0-2, y0-1 -> slots 0,1; zero the accumulators that window row y0-1 will add into
+    load_row(g.y0 - 2);
+    bwd_place<S, 0>(st, nx, ny, ngw, nam);
+    load_row(g.y0 - 1);
+    bwd_place<S, 1>(st, nx, ny, ngw, nam);
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) st.ACC[0][s][c][k] = st.ACC[1][s][c][k] = 0.f;
+    load_row(g.y0);
+    float X[S][3], Y[3];
+    // step for new row r (slot SL): window row j = r-1 (slot M), output row t = r-2 (slot T) completes
+    const int rlast = g.yend + 1;  // output row t completes when row t+2 has arrived
+    for (int r = g.y0; r <= rlast; r += 3) {
+        {   // r in slot 2; window j=r-1 in slot 1; output t=r-2 in slot 0
+            bwd_place<S, 2>(st, nx, ny, ngw, nam);
+            if (r + 1 <= rlast) load_row(r + 1);
+            const int j = r - 1;
+            bwd_window<S, 0, 1, 2>(st, col_exists && j >= 0 && j < H, P.s_offset, wL, wR, wU(r), wD(r - 2));
+            if (r - 2 >= g.y0) { row_of(0, X, Y); emit(r - 2, 0, st.ACC[0], X, Y, st.GW[0], st.AM[0]); }
+        }
+        if (r + 1 > rlast) break;
+        {   // r+1 in slot 0; window in slot 2; output in slot 1
+            bwd_place<S, 0>(st, nx, ny, ngw, nam);
+            if (r + 2 <= rlast) load_row(r + 2);
+            const int j = r;
+            bwd_window<S, 1, 2, 0>(st, col_exists && j >= 0 && j < H, P.s_offset, wL, wR, wU(r + 1), wD(r - 1));
+            if (r - 1 >= g.y0) { row_of(1, X, Y); emit(r - 1, 0, st.ACC[1], X, Y, st.GW[1], st.AM[1]); }
+        }
+        if (r + 2 > rlast) break;
+        {   // r+2 in slot 1; window in slot 0; output in slot 2
+            bwd_place<S, 1>(st, nx, ny, ngw, nam);
+            if (r + 3 <= rlast) load_row(r + 3);
+            const int j = r + 1;
+            bwd_window<S, 2, 0, 1>(st, col_exists && j >= 0 && j < H, P.s_offset, wL, wR, wU(r + 2), wD(r));
+            { row_of(2, X, Y); emit(r, 0, st.ACC[2], X, Y, st.GW[2], st.AM[2]); }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SSIM-only backward (autograd of metrics.reprojection_error w.r.t. preds), one plane per "image"
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kWaves) void ssim_bwd_kernel(const float* __restrict__ preds,
+                                                               const float* __restrict__ targets,
+                                                               const float* __restrict__ g_out, int nplanes, int H, int W,
+                                                               int nbx, int nby, int RB, float* __restrict__ g_preds) {
+    const BandGeom g = band_geom<2>(nplanes, H, W, nbx, nby, RB);
+    if (!g.active) return;
+    const size_t HW = (size_t)H * W;
+    const float* xp = preds + (size_t)g.b * HW + g.cl;
+    const float* yp = targets + (size_t)g.b * HW + g.cl;
+    const float* wp = g_out + (size_t)g.b * HW + g.cl;
+    float* gp = g_preds + (size_t)g.b * HW + g.col;
+    const bool col_exists = g.col >= 0 && g.col < W;
+    const bool lane_out = g.lane >= 2 && g.lane <= 61 && g.col < W;
+    const float wL = g.col == 1 ? 2.0f : 1.0f, wR = g.col == W - 2 ? 2.0f : 1.0f;
+    float X[3], XX[3], XY[3], Y[3], YY[3], GW[3], ACC[3][3];
+    auto place = [&](int slot, int r) {
+        const size_t ro = (size_t)reflect_idx(r, H) * W;
+        float x = xp[ro], y = yp[ro];
+        X[slot] = x; Y[slot] = y; XX[slot] = x * x; YY[slot] = y * y; XY[slot] = x * y;
+        GW[slot] = wp[ro];
+    };
+    auto window = [&](int T, int M, int Bt, bool exists, float ax, float ay, float axx, float ayy, float axy, float wUn,
+                      float wDp) {
+        TgtStats ts;
+        target_stats(ay, ayy, ts);
+        SsimOut so;
+        ssim_from_sums(ax, axx, axy, ts, so);
+        const float gv = (exists && so.v >= 0.0f && so.v <= 1.0f) ? GW[M] : 0.0f;
+        const Coef k = ssim_coefs(so, ts, gv);
+        const float h[3] = {fmaf(wL, lane_left(k.A), fmaf(wR, lane_right(k.A), k.A)),
+                            fmaf(wL, lane_left(k.Bc), fmaf(wR, lane_right(k.Bc), k.Bc)),
+                            fmaf(wL, lane_left(k.Cc), fmaf(wR, lane_right(k.Cc), k.Cc))};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ACC[Bt][i] = wUn * h[i];
+            ACC[M][i] += h[i];
+            ACC[T][i] = fmaf(wDp, h[i], ACC[T][i]);
+        }
+    };
+    auto emit = [&](int t, int slot) {
+        if (lane_out) gp[(size_t)t * W] = fmaf(Y[slot], ACC[slot][2], fmaf(X[slot], ACC[slot][1], ACC[slot][0]));
+    };
+    auto wU = [&](int t) { return t == 1 ? 2.0f : 1.0f; };
+    auto wD = [&](int t) { return t == H - 2 ? 2.0f : 1.0f; };
+    place(0, g.y0 - 2);
+    place(1, g.y0 - 1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ACC[0][i] = ACC[1][i] = 0.f;
+    const int rlast = g.yend + 1;
+    for (int r = g.y0; r <= rlast; r += 3) {
+        place(2, r);
+        window(0, 1, 2, col_exists && r - 1 >= 0 && r - 1 < H, win9<0, 1, 2>(X), win9<0, 1, 2>(Y), win9<0, 1, 2>(XX),
+               win9<0, 1, 2>(YY), win9<0, 1, 2>(XY), wU(r), wD(r - 2));
+        if (r - 2 >= g.y0) emit(r - 2, 0);
+        if (r + 1 > rlast) break;
+        place(0, r + 1);
+        window(1, 2, 0, col_exists && r >= 0 && r < H, win9<1, 2, 0>(X), win9<1, 2, 0>(Y), win9<1, 2, 0>(XX),
+               win9<1, 2, 0>(YY), win9<1, 2, 0>(XY), wU(r + 1), wD(r - 1));
+        if (r - 1 >= g.y0) emit(r - 1, 1);
+        if (r + 2 > rlast) break;
+        place(1, r + 2);
+        window(2, 0, 1, col_exists && r + 1 >= 0 && r + 1 < H, win9<2, 0, 1>(X), win9<2, 0, 1>(Y), win9<2, 0, 1>(XX),
+               win9<2, 0, 1>(YY), win9<2, 0, 1>(XY), wU(r + 2), wD(r));
+        emit(r, 2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host-side launch geometry
+// ---------------------------------------------------------------------------------------------------
+struct Geom { int nbx, nby, RB, nblocks, nwaves; };
+
+inline Geom make_geom(int B, int H, int W, int halo) {
+    Geom g;
+    const int useful = 64 - 2 * halo;
+    g.nbx = (W + useful - 1) / useful;
+    // rows per wave: enough waves to fill 256 CUs x 4 SIMDs a few times over, but keep the halo re-read small
+    int RB = 32;
+    while (RB > 8 && (long long)B * g.nbx * ((H + RB - 1) / RB) < 4096) RB >>= 1;
+    g.RB = RB;
+    g.nby = (H + RB - 1) / RB;
+    g.nwaves = B * g.nbx * g.nby;
+    g.nblocks = (g.nwaves + kWaves - 1) / kWaves;
+    return g;
+}
+
+inline bool bad_dims(int B, int S, int H, int W) {
+    return B <= 0 || S <= 0 || H < 2 || W < 2 || (long long)H * W > (1ll << 30) || (long long)B * H * W > (1ll << 31);
+}
+
+template <bool IDT>
+int launch_photo_fwd(int S, const PhotoFwdParams& P, int nblocks, hipStream_t st) {
+    dim3 g(nblocks), b(64 * kWaves);
+    switch (S) {
+        case 1: hipLaunchKernelGGL((photo_fwd_kernel<1, IDT>), g, b, 0, st, P); break;
+        case 2: hipLaunchKernelGGL((photo_fwd_kernel<2, IDT>), g, b, 0, st, P); break;
+        case 3: hipLaunchKernelGGL((photo_fwd_kernel<3, IDT>), g, b, 0, st, P); break;
+        case 4: hipLaunchKernelGGL((photo_fwd_kernel<4, IDT>), g, b, 0, st, P); break;
+        default: return DS_ERR_UNSUPPORTED;
+    }
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+template <bool FUSED>
+int launch_photo_bwd(int S, const PhotoBwdParams& P, int nblocks, hipStream_t st) {
+    dim3 g(nblocks), b(64 * kWaves);
+    switch (S) {
+        case 1: hipLaunchKernelGGL((photo_bwd_kernel<1, FUSED>), g, b, 0, st, P); break;
+        case 2: hipLaunchKernelGGL((photo_bwd_kernel<2, FUSED>), g, b, 0, st, P); break;
+        case 3: hipLaunchKernelGGL((photo_bwd_kernel<3, FUSED>), g, b, 0, st, P); break;
+        case 4: hipLaunchKernelGGL((photo_bwd_kernel<4, FUSED>), g, b, 0, st, P); break;
+        default: return DS_ERR_UNSUPPORTED;
+    }
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ds_ssim_fwd(const float* preds, const float* targets, int nplanes, int H, int W, float* out, void* stream) {
+    if (!preds || !targets || !out || bad_dims(nplanes, 1, H, W)) return DS_ERR_INVALID_ARG;
+    const Geom g = make_geom(nplanes, H, W, 1);
+    hipLaunchKernelGGL(ssim_fwd_kernel, dim3(g.nblocks), dim3(64 * kWaves), 0, (hipStream_t)stream, preds, targets, nplanes,
+                       H, W, g.nbx, g.nby, g.RB, out);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_ssim_bwd(const float* preds, const float* targets, const float* g_out, int nplanes, int H, int W, float* g_preds,
+                void* stream) {
+    if (!preds || !targets || !g_out || !g_preds || bad_dims(nplanes, 1, H, W)) return DS_ERR_INVALID_ARG;
+    const Geom g = make_geom(nplanes, H, W, 2);
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3(g.nblocks), dim3(64 * kWaves), 0, (hipStream_t)stream, preds, targets, g_out,
+                       nplanes, H, W, g.nbx, g.nby, g.RB, g_preds);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_reprojection_loss_fwd(const float* preds, const float* targets, long long tgt_stride_b, long long tgt_stride_s,
+                             int B, int S, int H, int W, float* out, uint8_t* aux, void* stream) {
+    if (!preds || !targets || !out || bad_dims(B, S, H, W) || S > 32) return DS_ERR_INVALID_ARG;
+    const Geom g = make_geom(B, H, W, 1);
+    const long long HW = (long long)H * W;
+    PhotoFwdParams P{};
+    P.pred_stride_b = (long long)S * 3 * HW;
+    P.tgt_stride_b = tgt_stride_b;
+    P.B = B; P.H = H; P.W = W; P.nbx = g.nbx; P.nby = g.nby; P.RB = g.RB;
+    P.out = out; P.aux = aux;
+    // one launch per chunk of sources that share a target; per-source targets go one source at a time
+    const int chunk = tgt_stride_s == 0 ? DS_MAX_SOURCES : 1;
+    for (int s0 = 0; s0 < S; s0 += chunk) {
+        const int n = (S - s0) < chunk ? (S - s0) : chunk;
+        P.preds = preds + (long long)s0 * 3 * HW;
+        P.target = targets + (long long)s0 * tgt_stride_s;
+        P.s_offset = s0;
+        int rc = launch_photo_fwd<false>(n, P, g.nblocks, (hipStream_t)stream);
+        if (rc != DS_OK) return rc;
+    }
+    return DS_OK;
+}
+
+int ds_reprojection_loss_bwd(const float* preds, const float* targets, long long tgt_stride_b, long long tgt_stride_s,
+                             const float* g_out, const uint8_t* aux, int B, int S, int H, int W, float* g_preds,
+                             void* stream) {
+    if (!preds || !targets || !g_out || !aux || !g_preds || bad_dims(B, S, H, W) || S > 32) return DS_ERR_INVALID_ARG;
+    const Geom g = make_geom(B, H, W, 2);
+    const long long HW = (long long)H * W;
+    PhotoBwdParams P{};
+    P.pred_stride_b = (long long)S * 3 * HW;
+    P.tgt_stride_b = tgt_stride_b;
+    P.g_out = g_out; P.aux = aux;
+    P.B = B; P.H = H; P.W = W; P.nbx = g.nbx; P.nby = g.nby; P.RB = g.RB;
+    P.inv_hw = 1.0f;
+    const int chunk = tgt_stride_s == 0 ? DS_MAX_SOURCES : 1;
+    for (int s0 = 0; s0 < S; s0 += chunk) {
+        const int n = (S - s0) < chunk ? (S - s0) : chunk;
+        P.preds = preds + (long long)s0 * 3 * HW;
+        P.g_preds = g_preds + (long long)s0 * 3 * HW;
+        P.target = targets + (long long)s0 * tgt_stride_s;
+        P.s_offset = s0;
+        int rc = launch_photo_bwd<false>(n, P, g.nblocks, (hipStream_t)stream);
+        if (rc != DS_OK) return rc;
+    }
+    return DS_OK;
+}
+
+size_t ds_fused_loss_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H < 2 || W < 2) return 0;
+    const Geom g = make_geom(B, H, W, 1);
+    return (size_t)g.nblocks * kWaves * 2 * sizeof(float);
+}
+
+int ds_fused_loss_fwd(const float* warped, const float* src, const float* target, int B, int S, int H, int W,
+                      float* out_loss, float* idt_loss, uint8_t* aux, float* sums, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    if (!warped || !src || !target || !out_loss || !idt_loss || !aux || !sums || bad_dims(B, S, H, W))
+        return DS_ERR_INVALID_ARG;
+    if (S > DS_MAX_SOURCES) return DS_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < ds_fused_loss_workspace_bytes(B, H, W)) return DS_ERR_WORKSPACE;
+    const Geom g = make_geom(B, H, W, 1);
+    const long long HW = (long long)H * W;
+    PhotoFwdParams P{};
+    P.preds = warped; P.src = src; P.target = target;
+    P.pred_stride_b = (long long)S * 3 * HW;
+    P.tgt_stride_b = 3 * HW;
+    P.B = B; P.H = H; P.W = W; P.nbx = g.nbx; P.nby = g.nby; P.RB = g.RB;
+    P.out = out_loss; P.idt = idt_loss; P.aux = aux; P.wave_partials = (float*)workspace;
+    int rc = launch_photo_fwd<true>(S, P, g.nblocks, (hipStream_t)stream);
+    if (rc != DS_OK) return rc;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const float*)workspace,
+                       g.nbx * g.nby, 1.0 / (double)HW, sums);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_fused_loss_bwd(const float* warped, const float* target, const float* idt_loss, const uint8_t* aux,
+                      const float* g_sums, int B, int S, int H, int W, float* g_warped, void* stream) {
+    if (!warped || !target || !idt_loss || !aux || !g_sums || !g_warped || bad_dims(B, S, H, W)) return DS_ERR_INVALID_ARG;
+    if (S > DS_MAX_SOURCES) return DS_ERR_UNSUPPORTED;
+    const Geom g = make_geom(B, H, W, 2);
+    const long long HW = (long long)H * W;
+    PhotoBwdParams P{};
+    P.preds = warped; P.target = target; P.idt = idt_loss; P.g_sums = g_sums; P.aux = aux;
+    P.pred_stride_b = (long long)S * 3 * HW;
+    P.tgt_stride_b = 3 * HW;
+    P.B = B; P.H = H; P.W = W; P.nbx = g.nbx; P.nby = g.nby; P.RB = g.RB;
+    P.inv_hw = (float)(1.0 / (double)HW);
+    P.g_preds = g_warped;
+    return launch_photo_bwd<true>(S, P, g.nblocks, (hipStream_t)stream);
+}
+
+}  // extern "C"

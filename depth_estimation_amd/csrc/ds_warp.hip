@@ -1,0 +1,469 @@
+// ds_warp.hip -- back-project -> transform -> project -> bilinear gather, forward and backward.
+//
+// Reference: synthesis.reproject_from_depth (synthesis.py:83-116), synthesis.synthesize
+// (synthesis.py:36-54) and their autograd; callers train.py:72-77.
+//
+// All kernels here are one-thread-per-pixel streaming kernels: planar NCHW images, consecutive lanes
+// on consecutive x, so depth reads / warped writes are 256-B coalesced per wave and the 4x3 corner
+// gathers hit neighbouring source texels (L1/L2-resident lines).  HBM-bound by design; no LDS.
+#include "ds_common.h"
+#include "depthsynth.h"
+
+using namespace ds;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void reproject_kernel(const float* __restrict__ K, const float* __restrict__ Kinv,
+                                                             const float* __restrict__ pose,
+                                                             const float* __restrict__ depth, int H, int W,
+                                                             float* __restrict__ coords) {
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * kThreads + threadIdx.x;
+    if (p >= H * W) return;
+    Cam cam;
+    load_cam(cam, K, Kinv, pose + 12 * n);
+    const int y = p / W, x = p - y * W;
+    Proj pr;
+    project_pixel(cam, (float)x, (float)y, depth[(size_t)n * H * W + p], pr);
+    float2* o = reinterpret_cast<float2*>(coords) + (size_t)n * H * W + p;
+    *o = make_float2(pr.u, pr.v);
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(kThreads) void grid_sample_fwd_kernel(const float* __restrict__ src, float* __restrict__ grid,
+                                                                   int Cdyn, int Hs, int Ws, int H, int W,
+                                                                   float* __restrict__ out) {
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * kThreads + threadIdx.x;
+    if (p >= H * W) return;
+    const int Cc = C > 0 ? C : Cdyn;
+    float2* g = reinterpret_cast<float2*>(grid) + (size_t)n * H * W + p;
+    float2 uv = *g;
+    Samp s;
+    sample_setup(uv.x, uv.y, Hs, Ws, s);
+    *g = make_float2(s.gx, s.gy);  // the reference normalises its argument in place (synthesis.py:50-51)
+    Corners co;
+    corner_offsets(s, Hs, Ws, co);
+    const float* sp = src + (size_t)n * Cc * Hs * Ws;
+    float* op = out + (size_t)n * Cc * H * W + p;
+#pragma unroll
+    for (int c = 0; c < Cc; ++c) {
+        float nw, ne, sw, se;
+        gather4(sp + (size_t)c * Hs * Ws, co, nw, ne, sw, se);
+        op[(size_t)c * H * W] = bilinear(nw, ne, sw, se, s);
+    }
+}
+
+// grid gradient of one pixel from the corner texels (torch grid_sampler_2d backward, bilinear/border):
+// zero when the un-clipped coordinate lies on or outside the border; un-normalise * normalise factors.
+__device__ __forceinline__ void finish_grid_grad(const Samp& s, int Hs, int Ws, float& gix, float& giy) {
+    if (!(s.ixu > 0.0f && s.ixu < (float)(Ws - 1))) gix = 0.0f;
+    if (!(s.iyu > 0.0f && s.iyu < (float)(Hs - 1))) giy = 0.0f;
+    gix = gix * ((float)(Ws - 1) / 2.0f) * (2.0f / (float)(Ws - 1));
+    giy = giy * ((float)(Hs - 1) / 2.0f) * (2.0f / (float)(Hs - 1));
+}
+
+__device__ __forceinline__ void scatter_src_grad(float* __restrict__ gp, const Corners& co, const Samp& s, float g) {
+    if (g == 0.0f) return;
+    atomicAdd(gp + co.o_nw, g * s.w_nw);
+    if (co.xin) atomicAdd(gp + co.o_ne, g * s.w_ne);
+    if (co.yin) atomicAdd(gp + co.o_sw, g * s.w_sw);
+    if (co.xin && co.yin) atomicAdd(gp + co.o_se, g * s.w_se);
+}
+
+template <int C>
+__global__ __launch_bounds__(kThreads) void grid_sample_bwd_kernel(const float* __restrict__ src,
+                                                                   const float* __restrict__ grid_norm,
+                                                                   const float* __restrict__ g_out, int Cdyn, int Hs,
+                                                                   int Ws, int H, int W, float* __restrict__ g_grid,
+                                                                   float* __restrict__ g_src) {
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * kThreads + threadIdx.x;
+    if (p >= H * W) return;
+    const int Cc = C > 0 ? C : Cdyn;
+    float2 gn = reinterpret_cast<const float2*>(grid_norm)[(size_t)n * H * W + p];
+    Samp s;
+    sample_setup_norm(gn.x, gn.y, Hs, Ws, s);
+    Corners co;
+    corner_offsets(s, Hs, Ws, co);
+    const float* sp = src + (size_t)n * Cc * Hs * Ws;
+    const float* gp = g_out + (size_t)n * Cc * H * W + p;
+    float gix = 0.f, giy = 0.f;
+#pragma unroll
+    for (int c = 0; c < Cc; ++c) {
+        float nw, ne, sw, se;
+        gather4(sp + (size_t)c * Hs * Ws, co, nw, ne, sw, se);
+        float g = gp[(size_t)c * H * W];
+        gix = fmaf(g, fmaf(ne - nw, s.sy, (se - sw) * s.ny), gix);
+        giy = fmaf(g, fmaf(sw - nw, s.ex, (se - ne) * s.wx), giy);
+        if (g_src) scatter_src_grad(g_src + ((size_t)n * Cc + c) * Hs * Ws, co, s, g);
+    }
+    finish_grid_grad(s, Hs, Ws, gix, giy);
+    reinterpret_cast<float2*>(g_grid)[(size_t)n * H * W + p] = make_float2(gix, giy);
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(kThreads) void warp_fwd_kernel(const float* __restrict__ K, const float* __restrict__ Kinv,
+                                                            const float* __restrict__ pose,
+                                                            const float* __restrict__ depth,
+                                                            const float* __restrict__ src, int Cdyn, int Hs, int Ws,
+                                                            int H, int W, float* __restrict__ warped) {
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * kThreads + threadIdx.x;
+    if (p >= H * W) return;
+    const int Cc = C > 0 ? C : Cdyn;
+    Cam cam;
+    load_cam(cam, K, Kinv, pose + 12 * n);
+    const int y = p / W, x = p - y * W;
+    Proj pr;
+    project_pixel(cam, (float)x, (float)y, depth[(size_t)n * H * W + p], pr);
+    Samp s;
+    sample_setup(pr.u, pr.v, Hs, Ws, s);
+    Corners co;
+    corner_offsets(s, Hs, Ws, co);
+    const float* sp = src + (size_t)n * Cc * Hs * Ws;
+    float* op = warped + (size_t)n * Cc * H * W + p;
+#pragma unroll
+    for (int c = 0; c < Cc; ++c) {
+        float nw, ne, sw, se;
+        gather4(sp + (size_t)c * Hs * Ws, co, nw, ne, sw, se);
+        op[(size_t)c * H * W] = bilinear(nw, ne, sw, se, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// warp backward: per pixel g_depth; per (n) 12-float pose gradient reduced wave -> block -> partial
+// buffer -> pose_finalize_kernel (fixed order: deterministic, no atomics); optional image scatter.
+constexpr int kBwdPix = 4;  // pixels per thread
+
+// autograd of project_pixel: (g_u, g_v) = d loss / d(u, v) -> g_depth, += pose gradient
+__device__ __forceinline__ void project_bwd_pixel(const Cam& cam, const Proj& pr, float gix, float giy, float& g_d,
+                                                  float (&gM)[12]) {
+    const float rz = 1.0f / pr.z;
+    float gq0 = gix * rz, gq1 = giy * rz;
+    float gq2 = (fabsf(pr.q[2]) < 1e-6f) ? 0.0f : -(fmaf(pr.u, gix, pr.v * giy)) * rz;
+    float gT[3], gP[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gT[k] = fmaf(cam.K[6 + k], gq2, fmaf(cam.K[3 + k], gq1, cam.K[k] * gq0));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gP[i] = fmaf(cam.M[8 + i], gT[2], fmaf(cam.M[4 + i], gT[1], cam.M[i] * gT[0]));
+    g_d = fmaf(pr.c[2], gP[2], fmaf(pr.c[1], gP[1], pr.c[0] * gP[0]));
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        gM[4 * j + 0] = fmaf(gT[j], pr.P[0], gM[4 * j + 0]);
+        gM[4 * j + 1] = fmaf(gT[j], pr.P[1], gM[4 * j + 1]);
+        gM[4 * j + 2] = fmaf(gT[j], pr.P[2], gM[4 * j + 2]);
+        gM[4 * j + 3] += gT[j];
+    }
+}
+
+// block-level reduction of 12 floats per thread -> partial[12]; every thread of the block must call it
+__device__ __forceinline__ void block_reduce12(float (&gM)[12], float* __restrict__ partial, float (*lds)[12]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) gM[i] = wave_sum(gM[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) lds[wave][i] = gM[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        float a = 0.f;
+        for (int w = 0; w < nw; ++w) a += lds[w][threadIdx.x];
+        partial[threadIdx.x] = a;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restrict__ K, const float* __restrict__ Kinv,
+                                                            const float* __restrict__ pose,
+                                                            const float* __restrict__ depth,
+                                                            const float* __restrict__ src,
+                                                            const float* __restrict__ g_warped, int Cdyn, int Hs, int Ws,
+                                                            int H, int W, float* __restrict__ g_depth,
+                                                            float* __restrict__ g_src, float* __restrict__ partials) {
+    __shared__ float lds[kThreads / 64][12];
+    const int n = blockIdx.y;
+    const int Cc = C > 0 ? C : Cdyn;
+    const int HW = H * W;
+    Cam cam;
+    load_cam(cam, K, Kinv, pose + 12 * n);
+    float gM[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) gM[i] = 0.f;
+    const float* sp = src + (size_t)n * Cc * Hs * Ws;
+#pragma unroll
+    for (int it = 0; it < kBwdPix; ++it) {
+        const int p = (blockIdx.x * kBwdPix + it) * kThreads + threadIdx.x;
+        if (p < HW) {
+            const int y = p / W, x = p - y * W;
+            Proj pr;
+            project_pixel(cam, (float)x, (float)y, depth[(size_t)n * HW + p], pr);
+            Samp s;
+            sample_setup(pr.u, pr.v, Hs, Ws, s);
+            Corners co;
+            corner_offsets(s, Hs, Ws, co);
+            const float* gp = g_warped + (size_t)n * Cc * HW + p;
+            float gix = 0.f, giy = 0.f;
+#pragma unroll
+            for (int c = 0; c < Cc; ++c) {
+                float nw, ne, sw, se;
+                gather4(sp + (size_t)c * Hs * Ws, co, nw, ne, sw, se);
+                float g = gp[(size_t)c * HW];
+                gix = fmaf(g, fmaf(ne - nw, s.sy, (se - sw) * s.ny), gix);
+                giy = fmaf(g, fmaf(sw - nw, s.ex, (se - ne) * s.wx), giy);
+                if (g_src) scatter_src_grad(g_src + ((size_t)n * Cc + c) * Hs * Ws, co, s, g);
+            }
+            float gd;
+            finish_grid_grad(s, Hs, Ws, gix, giy);
+            project_bwd_pixel(cam, pr, gix, giy, gd, gM);
+            g_depth[(size_t)n * HW + p] = gd;
+        }
+    }
+    block_reduce12(gM, partials + ((size_t)n * gridDim.x + blockIdx.x) * 12, lds);
+}
+
+// backward of reproject_from_depth alone: g_coords (N,H,W,2) -> g_depth, pose partials
+__global__ __launch_bounds__(kThreads) void reproject_bwd_kernel(const float* __restrict__ K, const float* __restrict__ Kinv,
+                                                                 const float* __restrict__ pose,
+                                                                 const float* __restrict__ depth,
+                                                                 const float* __restrict__ g_coords, int H, int W,
+                                                                 float* __restrict__ g_depth, float* __restrict__ partials) {
+    __shared__ float lds[kThreads / 64][12];
+    const int n = blockIdx.y;
+    const int HW = H * W;
+    Cam cam;
+    load_cam(cam, K, Kinv, pose + 12 * n);
+    float gM[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) gM[i] = 0.f;
+#pragma unroll
+    for (int it = 0; it < kBwdPix; ++it) {
+        const int p = (blockIdx.x * kBwdPix + it) * kThreads + threadIdx.x;
+        if (p < HW) {
+            const int y = p / W, x = p - y * W;
+            Proj pr;
+            project_pixel(cam, (float)x, (float)y, depth[(size_t)n * HW + p], pr);
+            const float2 g = reinterpret_cast<const float2*>(g_coords)[(size_t)n * HW + p];
+            float gd;
+            project_bwd_pixel(cam, pr, g.x, g.y, gd, gM);
+            g_depth[(size_t)n * HW + p] = gd;
+        }
+    }
+    block_reduce12(gM, partials + ((size_t)n * gridDim.x + blockIdx.x) * 12, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a1: synthesis.construct_pose_batch (synthesis.py:6-33) and its autograd, one thread per pose
+// ---------------------------------------------------------------------------------------------------
+__global__ void pose_from_vec_fwd_kernel(const float* __restrict__ vec, int N, float* __restrict__ pose) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* r = vec + 6 * n;
+    const float th = sqrtf((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+    const float den = th + 1e-6f;
+    const float u0 = r[0] / den, u1 = r[1] / den, u2 = r[2] / den;
+    const float U[9] = {0.f, -u2, u1, u2, 0.f, -u0, -u1, u0, 0.f};
+    const float s = sinf(th), c1 = 1.0f - cosf(th);
+    float* P = pose + 12 * n;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float uu = U[3 * i] * U[j];
+            uu = fmaf(U[3 * i + 1], U[3 + j], uu);
+            uu = fmaf(U[3 * i + 2], U[6 + j], uu);
+            P[4 * i + j] = ((i == j ? 1.0f : 0.0f) + s * U[3 * i + j]) + c1 * uu;
+        }
+        P[4 * i + 3] = r[3 + i];
+    }
+}
+
+__global__ void pose_from_vec_bwd_kernel(const float* __restrict__ vec, const float* __restrict__ g_pose, int N,
+                                         float* __restrict__ g_vec) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* r = vec + 6 * n;
+    const float* G4 = g_pose + 12 * n;
+    const float th = sqrtf((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+    const float den = th + 1e-6f;
+    const float u[3] = {r[0] / den, r[1] / den, r[2] / den};
+    const float U[9] = {0.f, -u[2], u[1], u[2], 0.f, -u[0], -u[1], u[0], 0.f};
+    const float s = sinf(th), c = cosf(th), c1 = 1.0f - c;
+    float G[9], UU[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            G[3 * i + j] = G4[4 * i + j];
+            UU[3 * i + j] = U[3 * i] * U[j] + U[3 * i + 1] * U[3 + j] + U[3 * i + 2] * U[6 + j];
+        }
+    float g_s = 0.f, g_c1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        g_s += G[i] * U[i];
+        g_c1 += G[i] * UU[i];
+    }
+    // dL/dU = s*G + c1*(G U^T + U^T G)
+    float gU[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a += G[3 * i + k] * U[3 * j + k] + U[3 * k + i] * G[3 * k + j];
+            gU[3 * i + j] = s * G[3 * i + j] + c1 * a;
+        }
+    const float gu[3] = {gU[7] - gU[5], gU[2] - gU[6], gU[3] - gU[1]};
+    float g_th = c * g_s + s * g_c1;
+    float gr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gr[k] = gu[k] / den;
+        g_th -= gu[k] * r[k] / (den * den);
+    }
+    if (th > 0.f) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gr[k] += g_th * r[k] / th;
+    }
+    float* o = g_vec + 6 * n;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = gr[k];
+        o[3 + k] = G4[4 * k + 3];
+    }
+}
+
+// partials (N, nblk, 12) -> g_pose (N,12): fixed summation order, double accumulator
+__global__ void pose_finalize_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ g_pose) {
+    const int n = blockIdx.x, i = threadIdx.x;
+    if (i >= 12) return;
+    double a = 0.0;
+    for (int b = 0; b < nblk; ++b) a += (double)partials[((size_t)n * nblk + b) * 12 + i];
+    g_pose[n * 12 + i] = (float)a;
+}
+
+inline int pix_blocks(int HW) { return (HW + kThreads - 1) / kThreads; }
+inline int bwd_blocks(int HW) { return (HW + kThreads * kBwdPix - 1) / (kThreads * kBwdPix); }
+
+inline bool bad_dims(int N, int C, int Hs, int Ws, int H, int W) {
+    return N <= 0 || C <= 0 || Hs < 2 || Ws < 2 || H <= 0 || W <= 0 || N > 65535 ||
+           (long long)H * W > (1ll << 30) || (long long)Hs * Ws > (1ll << 30);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ds_reproject(const float* K, const float* Kinv, const float* pose, const float* depth, int N, int H, int W,
+                 float* coords, void* stream) {
+    if (!K || !Kinv || !pose || !depth || !coords || bad_dims(N, 1, 2, 2, H, W)) return DS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(reproject_kernel, dim3(pix_blocks(H * W), N), dim3(kThreads), 0, (hipStream_t)stream, K, Kinv, pose,
+                       depth, H, W, coords);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_grid_sample_fwd(const float* src, float* grid, int N, int C, int Hs, int Ws, int H, int W, float* out,
+                       void* stream) {
+    if (!src || !grid || !out || bad_dims(N, C, Hs, Ws, H, W)) return DS_ERR_INVALID_ARG;
+    dim3 g(pix_blocks(H * W), N), b(kThreads);
+    if (C == 3)
+        hipLaunchKernelGGL(grid_sample_fwd_kernel<3>, g, b, 0, (hipStream_t)stream, src, grid, C, Hs, Ws, H, W, out);
+    else
+        hipLaunchKernelGGL(grid_sample_fwd_kernel<0>, g, b, 0, (hipStream_t)stream, src, grid, C, Hs, Ws, H, W, out);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_grid_sample_bwd(const float* src, const float* grid_norm, const float* g_out, int N, int C, int Hs, int Ws,
+                       int H, int W, float* g_grid, float* g_src, void* stream) {
+    if (!src || !grid_norm || !g_out || !g_grid || bad_dims(N, C, Hs, Ws, H, W)) return DS_ERR_INVALID_ARG;
+    dim3 g(pix_blocks(H * W), N), b(kThreads);
+    if (C == 3)
+        hipLaunchKernelGGL(grid_sample_bwd_kernel<3>, g, b, 0, (hipStream_t)stream, src, grid_norm, g_out, C, Hs, Ws, H, W,
+                           g_grid, g_src);
+    else
+        hipLaunchKernelGGL(grid_sample_bwd_kernel<0>, g, b, 0, (hipStream_t)stream, src, grid_norm, g_out, C, Hs, Ws, H, W,
+                           g_grid, g_src);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_warp_fwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src, int N,
+                int C, int Hs, int Ws, int H, int W, float* warped, void* stream) {
+    if (!K || !Kinv || !pose || !depth || !src || !warped || bad_dims(N, C, Hs, Ws, H, W)) return DS_ERR_INVALID_ARG;
+    dim3 g(pix_blocks(H * W), N), b(kThreads);
+    if (C == 3)
+        hipLaunchKernelGGL(warp_fwd_kernel<3>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, C, Hs, Ws, H, W,
+                           warped);
+    else
+        hipLaunchKernelGGL(warp_fwd_kernel<0>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, C, Hs, Ws, H, W,
+                           warped);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+size_t ds_warp_bwd_workspace_bytes(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)N * bwd_blocks(H * W) * 12 * sizeof(float);
+}
+
+int ds_warp_bwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                const float* g_warped, int N, int C, int Hs, int Ws, int H, int W, float* g_depth, float* g_pose,
+                float* g_src, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!K || !Kinv || !pose || !depth || !src || !g_warped || !g_depth || !g_pose || bad_dims(N, C, Hs, Ws, H, W))
+        return DS_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < ds_warp_bwd_workspace_bytes(N, H, W)) return DS_ERR_WORKSPACE;
+    const int nblk = bwd_blocks(H * W);
+    dim3 g(nblk, N), b(kThreads);
+    float* partials = (float*)workspace;
+    if (C == 3)
+        hipLaunchKernelGGL(warp_bwd_kernel<3>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, g_warped, C, Hs, Ws,
+                           H, W, g_depth, g_src, partials);
+    else
+        hipLaunchKernelGGL(warp_bwd_kernel<0>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, g_warped, C, Hs, Ws,
+                           H, W, g_depth, g_src, partials);
+    DS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pose_finalize_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, partials, nblk, g_pose);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_reproject_bwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* g_coords,
+                     int N, int H, int W, float* g_depth, float* g_pose, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+    if (!K || !Kinv || !pose || !depth || !g_coords || !g_depth || !g_pose || bad_dims(N, 1, 2, 2, H, W))
+        return DS_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < ds_warp_bwd_workspace_bytes(N, H, W)) return DS_ERR_WORKSPACE;
+    const int nblk = bwd_blocks(H * W);
+    float* partials = (float*)workspace;
+    hipLaunchKernelGGL(reproject_bwd_kernel, dim3(nblk, N), dim3(kThreads), 0, (hipStream_t)stream, K, Kinv, pose, depth,
+                       g_coords, H, W, g_depth, partials);
+    DS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pose_finalize_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, partials, nblk, g_pose);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_pose_from_vec_fwd(const float* vec, int N, float* pose, void* stream) {
+    if (!vec || !pose || N <= 0) return DS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(pose_from_vec_fwd_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, vec, N, pose);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_pose_from_vec_bwd(const float* vec, const float* g_pose, int N, float* g_vec, void* stream) {
+    if (!vec || !g_pose || !g_vec || N <= 0) return DS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(pose_from_vec_bwd_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, vec, g_pose, N, g_vec);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+"""Batched, fused entry points: the whole of train.py:72-92 for B targets x S sources in a handful of
+kernel launches, with autograd to depth, pose (and optionally the source images)."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+def intrinsics(width: int, height: int, device=None):
+    """The reference's camera (constants.py:25-44): normalised K with rows scaled by (W,H), and its pinv."""
+    K = torch.tensor([[0.58, 0.00, 0.50, 0.00], [0.00, 1.92, 0.50, 0.00], [0.00, 0.00, 1.00, 0.00],
+                      [0.00, 0.00, 0.00, 1.00]], dtype=torch.float32)
+    K[0, :] *= width
+    K[1, :] *= height
+    Kinv = torch.linalg.pinv(K)
+    return K.to(device), Kinv.to(device)
+
+
+def fused_reprojection_loss(src: torch.Tensor, target: torch.Tensor, depth: torch.Tensor, pose: torch.Tensor,
+                            K: torch.Tensor, Kinv: torch.Tensor, image_grad: bool = False):
+    """src (B,S,3,Hs,Ws), target (B,3,H,W), depth (B,S,1,H,W) [metres], pose (B,S,3,4).
+
+    Returns dict(loss (B,) = mean(out/exp(idt+1e-6)) per target (train.py:88), log (B,) = mean(out)
+    (train.py:92), warped (B,S,3,H,W), out_loss, idt_loss (B,H,W), aux (B,H,W) u8).
+    `loss` is differentiable w.r.t. depth and pose (and src through the warp when image_grad=True; the
+    identity term never back-propagates, as in the reference where src carries no grad)."""
+    b, s = src.shape[:2]
+    c, hs, ws = src.shape[2:]
+    h, w = target.shape[-2:]
+    src_w = src if image_grad else src.detach()
+    warped = ops.warp(K, Kinv, pose.reshape(b * s, 3, 4), depth.reshape(b * s, h, w), src_w.reshape(b * s, c, hs, ws))
+    warped = warped.reshape(b, s, c, h, w)
+    sums, out_loss, idt_loss, aux = ops.fused_loss(warped, src.detach(), target)
+    return dict(loss=sums[:, 0], log=sums[:, 1], warped=warped, out_loss=out_loss, idt_loss=idt_loss, aux=aux)
+
+
+def train_step_loss(src, target, depth, pose, K, Kinv, max_depth: float = 80.0, smooth_weight: float = 0.02):
+    """Summed training loss of train.py:83-89 over the B targets: sum_b [ mean(out/exp(idt+1e-6)) +
+    0.02 * regularization_term(depth_b/80, target_b stacked S times) ]."""
+    b, s = src.shape[:2]
+    r = fused_reprojection_loss(src, target, depth, pose, K, Kinv)
+    loss = r["loss"].sum()
+    h, w = target.shape[-2:]
+    tg = target.unsqueeze(1).expand(b, s, 3, h, w)
+    for i in range(b):  # the reference's regularization mean is per sample (N = S maps)
+        loss = loss + smooth_weight * ops.smoothness(depth[i] / max_depth, tg[i].contiguous())
+    r["total"] = loss
+    return r

@@ -1,0 +1,414 @@
+"""Batched operators over libdepthsynth.so with torch autograd.
+
+These are the building blocks; `synthesis.py` / `metrics.py` expose them under the reference's names and
+call signatures, `fused.py` chains them into the whole reprojection loss of train.py:72-92.
+Outputs and workspaces are torch tensors allocated here; the kernels never allocate.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _chk_cam(K, Kinv, pose, n):
+    K, Kinv, pose = L.dev_f32(K, "intrinsic_mat"), L.dev_f32(Kinv, "intrinsic_inv"), L.dev_f32(pose, "pose_mat")
+    if K.shape != (4, 4) or Kinv.shape != (4, 4):
+        raise RuntimeError(f"intrinsics must be (4,4), got {tuple(K.shape)} / {tuple(Kinv.shape)}")
+    if pose.shape != (n, 3, 4):
+        raise RuntimeError(f"pose must be ({n},3,4), got {tuple(pose.shape)}")
+    return K, Kinv, pose
+
+
+# ----------------------------------------------------------------------------------------------------
+# synthesis.construct_pose_batch
+# ----------------------------------------------------------------------------------------------------
+class _PoseFromVec(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vec):
+        vec = L.dev_f32(vec, "pose_vectors")
+        if vec.dim() != 2 or vec.shape[1] != 6:
+            raise RuntimeError(f"pose_vectors must be (N,6), got {tuple(vec.shape)}")
+        n = vec.shape[0]
+        pose = torch.empty(n, 3, 4, dtype=torch.float32, device=vec.device)
+        L.check(L.lib().ds_pose_from_vec_fwd(vec.data_ptr(), n, pose.data_ptr(), L.stream()), "ds_pose_from_vec_fwd")
+        ctx.save_for_backward(vec)
+        return pose
+
+    @staticmethod
+    def backward(ctx, g):
+        (vec,) = ctx.saved_tensors
+        g = L.dev_f32(g, "grad")
+        gv = torch.empty_like(vec)
+        L.check(L.lib().ds_pose_from_vec_bwd(vec.data_ptr(), g.data_ptr(), vec.shape[0], gv.data_ptr(), L.stream()),
+                "ds_pose_from_vec_bwd")
+        return gv
+
+
+def pose_from_vec(vec: torch.Tensor) -> torch.Tensor:
+    return _PoseFromVec.apply(vec)
+
+
+# ----------------------------------------------------------------------------------------------------
+# synthesis.reproject_from_depth (batched)
+# ----------------------------------------------------------------------------------------------------
+class _Reproject(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, K, Kinv, pose, depth):
+        depth = L.dev_f32(depth, "depth_map")
+        n, h, w = depth.shape
+        K, Kinv, pose = _chk_cam(K, Kinv, pose, n)
+        L.same_device(depth, K, Kinv, pose)
+        coords = torch.empty(n, h, w, 2, dtype=torch.float32, device=depth.device)
+        L.check(L.lib().ds_reproject(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), n, h, w,
+                                     coords.data_ptr(), L.stream()), "ds_reproject")
+        ctx.save_for_backward(K, Kinv, pose, depth)
+        return coords
+
+    @staticmethod
+    def backward(ctx, g):
+        K, Kinv, pose, depth = ctx.saved_tensors
+        n, h, w = depth.shape
+        g = L.dev_f32(g, "grad")
+        gd = torch.empty_like(depth)
+        gp = torch.empty_like(pose)
+        nb = L.lib().ds_warp_bwd_workspace_bytes(n, h, w)
+        ws = L.workspace.get(nb, depth.device)
+        L.check(L.lib().ds_reproject_bwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), g.data_ptr(), n,
+                                         h, w, gd.data_ptr(), gp.data_ptr(), ws.data_ptr(), nb, L.stream()),
+                "ds_reproject_bwd")
+        return None, None, gp, gd
+
+
+def reproject(K, Kinv, pose, depth) -> torch.Tensor:
+    """pose (N,3,4), depth (N,H,W) -> (N,H,W,2) pixel coords."""
+    return _Reproject.apply(K, Kinv, pose, depth)
+
+
+# ----------------------------------------------------------------------------------------------------
+# synthesis.synthesize (grid_sample with in-place normalisation of the grid)
+# ----------------------------------------------------------------------------------------------------
+class _GridSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, grid):
+        # src (N,C,Hs,Ws) contiguous, grid (N,H,W,2) contiguous, mutated in place
+        n, c, hs, ws = src.shape
+        _, h, w, _ = grid.shape
+        out = torch.empty(n, c, h, w, dtype=torch.float32, device=src.device)
+        L.check(L.lib().ds_grid_sample_fwd(src.data_ptr(), grid.data_ptr(), n, c, hs, ws, h, w, out.data_ptr(), L.stream()),
+                "ds_grid_sample_fwd")
+        ctx.mark_dirty(grid)
+        ctx.save_for_backward(src, grid)
+        ctx.src_needs_grad = src.requires_grad
+        return out, grid
+
+    @staticmethod
+    def backward(ctx, g_out, _g_grid_unused):
+        src, grid = ctx.saved_tensors
+        n, c, hs, ws = src.shape
+        _, h, w, _ = grid.shape
+        g_out = L.dev_f32(g_out, "grad")
+        g_grid = torch.empty_like(grid)
+        g_src = torch.zeros_like(src) if ctx.needs_input_grad[0] else None
+        L.check(L.lib().ds_grid_sample_bwd(src.data_ptr(), grid.data_ptr(), g_out.data_ptr(), n, c, hs, ws, h, w,
+                                           g_grid.data_ptr(), L.ptr(g_src), L.stream()), "ds_grid_sample_bwd")
+        if _g_grid_unused is not None:
+            # gradient arriving through later uses of the (now normalised) grid: chain rule of the in-place
+            # normalisation gx = u*2/(Ws-1) - 1
+            scale = torch.tensor([2.0 / (ws - 1), 2.0 / (hs - 1)], dtype=torch.float32, device=grid.device)
+            g_grid = g_grid + _g_grid_unused * scale
+        return g_src, g_grid
+
+
+def grid_sample_(src: torch.Tensor, grid: torch.Tensor) -> torch.Tensor:
+    """In-place-normalising sampler: `grid` (N,H,W,2), contiguous, holds pixel coords and is overwritten."""
+    out, _ = _GridSample.apply(src, grid)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# fused reproject + sample
+# ----------------------------------------------------------------------------------------------------
+class _Warp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, K, Kinv, pose, depth, src):
+        depth, src = L.dev_f32(depth, "depth"), L.dev_f32(src, "src")
+        n, h, w = depth.shape
+        if src.dim() != 4 or src.shape[0] != n:
+            raise RuntimeError(f"src must be ({n},C,Hs,Ws), got {tuple(src.shape)}")
+        _, c, hs, ws = src.shape
+        K, Kinv, pose = _chk_cam(K, Kinv, pose, n)
+        L.same_device(depth, src, K, Kinv, pose)
+        warped = torch.empty(n, c, h, w, dtype=torch.float32, device=src.device)
+        L.check(L.lib().ds_warp_fwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(), n, c,
+                                    hs, ws, h, w, warped.data_ptr(), L.stream()), "ds_warp_fwd")
+        ctx.save_for_backward(K, Kinv, pose, depth, src)
+        return warped
+
+    @staticmethod
+    def backward(ctx, g):
+        K, Kinv, pose, depth, src = ctx.saved_tensors
+        n, h, w = depth.shape
+        _, c, hs, ws = src.shape
+        g = L.dev_f32(g, "grad")
+        gd = torch.empty_like(depth)
+        gp = torch.empty_like(pose)
+        gs = torch.zeros_like(src) if ctx.needs_input_grad[4] else None
+        nb = L.lib().ds_warp_bwd_workspace_bytes(n, h, w)
+        wsb = L.workspace.get(nb, depth.device)
+        L.check(L.lib().ds_warp_bwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
+                                    g.data_ptr(), n, c, hs, ws, h, w, gd.data_ptr(), gp.data_ptr(), L.ptr(gs),
+                                    wsb.data_ptr(), nb, L.stream()), "ds_warp_bwd")
+        return None, None, gp, gd, gs
+
+
+def warp(K, Kinv, pose, depth, src) -> torch.Tensor:
+    """pose (N,3,4), depth (N,H,W), src (N,C,Hs,Ws) -> warped (N,C,H,W)."""
+    return _Warp.apply(K, Kinv, pose, depth, src)
+
+
+# ----------------------------------------------------------------------------------------------------
+# metrics.reprojection_error
+# ----------------------------------------------------------------------------------------------------
+class _Ssim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, preds, targets):
+        preds, targets = L.dev_f32(preds, "preds"), L.dev_f32(targets, "targets")
+        if preds.shape != targets.shape:
+            raise RuntimeError(f"preds {tuple(preds.shape)} and targets {tuple(targets.shape)} must have the same shape")
+        L.same_device(preds, targets)
+        h, w = preds.shape[-2:]
+        out = torch.empty_like(preds)
+        L.check(L.lib().ds_ssim_fwd(preds.data_ptr(), targets.data_ptr(), preds.numel() // (h * w), h, w, out.data_ptr(),
+                                    L.stream()), "ds_ssim_fwd")
+        ctx.save_for_backward(preds, targets)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        preds, targets = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise RuntimeError("reprojection_error: gradient w.r.t. targets is not implemented "
+                               "(no caller in the reference needs it)")
+        h, w = preds.shape[-2:]
+        g = L.dev_f32(g, "grad")
+        gp = torch.empty_like(preds)
+        L.check(L.lib().ds_ssim_bwd(preds.data_ptr(), targets.data_ptr(), g.data_ptr(), preds.numel() // (h * w), h, w,
+                                    gp.data_ptr(), L.stream()), "ds_ssim_bwd")
+        return gp, None
+
+
+def ssim_loss(preds, targets) -> torch.Tensor:
+    return _Ssim.apply(preds, targets)
+
+
+# ----------------------------------------------------------------------------------------------------
+# metrics.reprojection_loss (batched: preds (B,S,3,H,W))
+# ----------------------------------------------------------------------------------------------------
+class _ReprojLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, preds, targets, shared_target: bool):
+        preds, targets = L.dev_f32(preds, "preds"), L.dev_f32(targets, "targets")
+        L.same_device(preds, targets)
+        b, s, c, h, w = preds.shape
+        if c != 3:
+            raise RuntimeError(f"reprojection_loss kernels are built for 3 channels, got {c}")
+        hw = h * w
+        if shared_target:
+            if targets.shape != (b, c, h, w):
+                raise RuntimeError(f"targets must be ({b},{c},{h},{w}), got {tuple(targets.shape)}")
+            sb, ss = c * hw, 0
+        else:
+            if targets.shape != preds.shape:
+                raise RuntimeError(f"targets {tuple(targets.shape)} must match preds {tuple(preds.shape)}")
+            sb, ss = s * c * hw, c * hw
+        out = torch.empty(b, h, w, dtype=torch.float32, device=preds.device)
+        aux = torch.empty(b, h, w, dtype=torch.uint8, device=preds.device)
+        L.check(L.lib().ds_reprojection_loss_fwd(preds.data_ptr(), targets.data_ptr(), sb, ss, b, s, h, w, out.data_ptr(),
+                                                 aux.data_ptr(), L.stream()), "ds_reprojection_loss_fwd")
+        ctx.save_for_backward(preds, targets, aux)
+        ctx.strides = (sb, ss)
+        ctx.mark_non_differentiable(aux)
+        return out, aux
+
+    @staticmethod
+    def backward(ctx, g_out, _g_aux):
+        preds, targets, aux = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise RuntimeError("reprojection_loss: gradient w.r.t. targets is not implemented")
+        b, s, c, h, w = preds.shape
+        sb, ss = ctx.strides
+        g_out = L.dev_f32(g_out, "grad")
+        gp = torch.empty_like(preds)
+        L.check(L.lib().ds_reprojection_loss_bwd(preds.data_ptr(), targets.data_ptr(), sb, ss, g_out.data_ptr(),
+                                                 aux.data_ptr(), b, s, h, w, gp.data_ptr(), L.stream()),
+                "ds_reprojection_loss_bwd")
+        return gp, None, None
+
+
+def reprojection_loss(preds, targets, shared_target: bool):
+    """preds (B,S,3,H,W); targets (B,3,H,W) if shared_target else (B,S,3,H,W) -> (out (B,H,W), aux (B,H,W) u8)."""
+    return _ReprojLoss.apply(preds, targets, shared_target)
+
+
+# ----------------------------------------------------------------------------------------------------
+# loss assembly train.py:80-92
+# ----------------------------------------------------------------------------------------------------
+class _FusedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, warped, src, target):
+        warped, src, target = L.dev_f32(warped, "warped"), L.dev_f32(src, "src"), L.dev_f32(target, "target")
+        L.same_device(warped, src, target)
+        b, s, c, h, w = warped.shape
+        if c != 3 or src.shape != warped.shape or target.shape != (b, c, h, w):
+            raise RuntimeError(f"expected warped/src (B,S,3,H,W) and target (B,3,H,W); got {tuple(warped.shape)}, "
+                               f"{tuple(src.shape)}, {tuple(target.shape)}")
+        dev = warped.device
+        out = torch.empty(b, h, w, dtype=torch.float32, device=dev)
+        idt = torch.empty(b, h, w, dtype=torch.float32, device=dev)
+        aux = torch.empty(b, h, w, dtype=torch.uint8, device=dev)
+        sums = torch.empty(b, 2, dtype=torch.float32, device=dev)
+        nb = L.lib().ds_fused_loss_workspace_bytes(b, h, w)
+        ws = L.workspace.get(nb, dev)
+        L.check(L.lib().ds_fused_loss_fwd(warped.data_ptr(), src.data_ptr(), target.data_ptr(), b, s, h, w, out.data_ptr(),
+                                          idt.data_ptr(), aux.data_ptr(), sums.data_ptr(), ws.data_ptr(), nb, L.stream()),
+                "ds_fused_loss_fwd")
+        ctx.save_for_backward(warped, target, idt, aux)
+        ctx.mark_non_differentiable(out, idt, aux)
+        return sums, out, idt, aux
+
+    @staticmethod
+    def backward(ctx, g_sums, _g_out, _g_idt, _g_aux):
+        warped, target, idt, aux = ctx.saved_tensors
+        b, s, c, h, w = warped.shape
+        # only sums[:,0] (the auto-masked mean, train.py:88) carries gradient; sums[:,1] is a log value
+        g0 = L.dev_f32(g_sums[:, 0], "grad")
+        gw = torch.empty_like(warped)
+        L.check(L.lib().ds_fused_loss_bwd(warped.data_ptr(), target.data_ptr(), idt.data_ptr(), aux.data_ptr(),
+                                          g0.data_ptr(), b, s, h, w, gw.data_ptr(), L.stream()), "ds_fused_loss_bwd")
+        return gw, None, None
+
+
+def fused_loss(warped, src, target):
+    """-> (sums (B,2), out_loss (B,H,W), idt_loss (B,H,W), aux (B,H,W) u8).  Differentiable through sums[:,0]
+    w.r.t. warped (the logged mean sums[:,1] is detached in the reference too: .item(), train.py:92)."""
+    return _FusedLoss.apply(warped, src, target)
+
+
+# ----------------------------------------------------------------------------------------------------
+# metrics.regularization_term
+# ----------------------------------------------------------------------------------------------------
+class _Smooth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depths, targets):
+        depths, targets = L.dev_f32(depths, "depths"), L.dev_f32(targets, "target_imgs")
+        L.same_device(depths, targets)
+        n, c, h, w = targets.shape
+        if depths.shape != (n, 1, h, w):
+            raise RuntimeError(f"depths must be ({n},1,{h},{w}), got {tuple(depths.shape)}")
+        val = torch.empty(1, dtype=torch.float32, device=depths.device)
+        nb = L.lib().ds_smooth_workspace_bytes(n, h, w)
+        ws = L.workspace.get(nb, depths.device)
+        L.check(L.lib().ds_smooth_fwd(depths.data_ptr(), targets.data_ptr(), n, c, h, w, val.data_ptr(), ws.data_ptr(), nb,
+                                      L.stream()), "ds_smooth_fwd")
+        ctx.save_for_backward(depths, targets)
+        return val.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        depths, targets = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise RuntimeError("regularization_term: gradient w.r.t. target_imgs is not implemented")
+        n, c, h, w = targets.shape
+        g = L.dev_f32(g.reshape(1), "grad")
+        gd = torch.empty_like(depths)
+        L.check(L.lib().ds_smooth_bwd(depths.data_ptr(), targets.data_ptr(), g.data_ptr(), n, c, h, w, gd.data_ptr(),
+                                      L.stream()), "ds_smooth_bwd")
+        return gd, None
+
+
+def smoothness(depths, targets) -> torch.Tensor:
+    return _Smooth.apply(depths, targets)
+
+
+# ----------------------------------------------------------------------------------------------------
+# forward-only ops
+# ----------------------------------------------------------------------------------------------------
+def depth_metrics(pred, gt) -> torch.Tensor:
+    """pred, gt (B,1,H,W) -> (8,) fp32: rmse, rmsle, abs_rel, sq_rel, delta1, delta2, delta3, n_valid."""
+    pred, gt = L.dev_f32(pred.detach(), "pred_depths"), L.dev_f32(gt.detach(), "depths")
+    L.same_device(pred, gt)
+    if pred.shape != gt.shape or pred.dim() < 3:
+        raise RuntimeError(f"pred {tuple(pred.shape)} and gt {tuple(gt.shape)} must both be (B,1,H,W)")
+    b = pred.shape[0]
+    hw = pred.numel() // b
+    h, w = pred.shape[-2], hw // pred.shape[-2]
+    out = torch.empty(8, dtype=torch.float32, device=pred.device)
+    nb = L.lib().ds_metrics_workspace_bytes(b, h, w)
+    ws = L.workspace.get(nb, pred.device)
+    L.check(L.lib().ds_depth_metrics(pred.data_ptr(), gt.data_ptr(), b, h, w, out.data_ptr(), ws.data_ptr(), nb, L.stream()),
+            "ds_depth_metrics")
+    return out
+
+
+def _depths_arg(depths):
+    d = np.ascontiguousarray(np.asarray(depths, dtype=np.float64).reshape(-1))
+    return d, d.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def synthesize_from_depths(K, Kinv, pose, depths, width, height, src) -> torch.Tensor:
+    src = L.dev_f32(src.detach(), "src_img")
+    if src.dim() == 4 and src.shape[0] == 1:
+        src = src[0]
+    if src.dim() != 3:
+        raise RuntimeError(f"src_img must be (C,H,W), got {tuple(src.shape)}")
+    c, hs, ws = src.shape
+    K, Kinv, pose = _chk_cam(K.detach(), Kinv.detach(), pose.detach().reshape(1, 3, 4), 1)
+    L.same_device(src, K, Kinv, pose)
+    d, dp = _depths_arg(depths)
+    out = torch.empty(len(d), c, int(height), int(width), dtype=torch.float32, device=src.device)
+    L.check(L.lib().ds_synthesize_from_depths(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), dp, len(d), src.data_ptr(), c,
+                                              hs, ws, int(height), int(width), out.data_ptr(), L.stream()),
+            "ds_synthesize_from_depths")
+    return out
+
+
+def cost_volume(target, synth) -> torch.Tensor:
+    target, synth = L.dev_f32(target.detach(), "target_img"), L.dev_f32(synth.detach(), "synthesized_imgs")
+    L.same_device(target, synth)
+    d, c, h, w = synth.shape
+    if target.numel() != c * h * w:
+        raise RuntimeError(f"target_img must be ({c},{h},{w}), got {tuple(target.shape)}")
+    out = torch.empty(d, h, w, dtype=torch.float32, device=synth.device)
+    L.check(L.lib().ds_cost_volume(target.data_ptr(), synth.data_ptr(), d, c, h, w, out.data_ptr(), L.stream()),
+            "ds_cost_volume")
+    return out
+
+
+def depth_from_costs(cost, sid: bool) -> torch.Tensor:
+    cost = L.dev_f32(cost.detach(), "cost_volumes")
+    n, d, h, w = cost.shape
+    out = torch.empty(n, 1, h, w, dtype=torch.float32, device=cost.device)
+    L.check(L.lib().ds_depth_from_costs(cost.data_ptr(), n, d, h, w, int(bool(sid)), out.data_ptr(), L.stream()),
+            "ds_depth_from_costs")
+    return out
+
+
+def plane_sweep_depth(K, Kinv, pose, depths, src, target_small, sid: bool = True) -> torch.Tensor:
+    """pose (NS,3,4), src (NS,C,Hs,Ws), target_small (C,H,W) -> candidate depth (NS,1,H,W) (train.py:49-59)."""
+    src, target_small = L.dev_f32(src.detach(), "src"), L.dev_f32(target_small.detach(), "target_small")
+    ns, c, hs, ws = src.shape
+    if target_small.dim() == 4:
+        target_small = target_small[0]
+    _, h, w = target_small.shape
+    K, Kinv, pose = _chk_cam(K.detach(), Kinv.detach(), pose.detach(), ns)
+    L.same_device(src, target_small, K, Kinv, pose)
+    d, dp = _depths_arg(depths)
+    out = torch.empty(ns, 1, h, w, dtype=torch.float32, device=src.device)
+    L.check(L.lib().ds_plane_sweep_depth(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), dp, len(d), src.data_ptr(),
+                                         target_small.data_ptr(), ns, c, hs, ws, h, w, int(bool(sid)), out.data_ptr(),
+                                         L.stream()), "ds_plane_sweep_depth")
+    return out

@@ -1,0 +1,147 @@
+/*
+ * depthsynth.h -- C ABI of libdepthsynth.so: gfx950 (MI355X) kernels for the view-synthesis /
+ * reprojection-loss hot path of banaga-benjamin/Depth_Estimation.
+ *
+ * The reference has no FFI: its interface for this path is the set of Python functions in
+ * synthesis.py and metrics.py, called from train.py:46-92, test.py:47-81 and predict.py:47-60.
+ * Each entry point below names the reference function (file:line) it replaces.  The Python mirror of
+ * those functions (depth_estimation_amd/synthesis.py, metrics.py) binds these symbols with ctypes;
+ * INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 (or uint8 where stated) unless marked HOST;
+ *   - images are planar NCHW, coordinate grids are (N,H,W,2) x-first -- the reference's layouts;
+ *   - K and Kinv are the reference's 4x4 row-major intrinsics (only [:3,:3] is read, synthesis.py:100,112);
+ *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous, never synchronise and
+ *     never allocate: the caller owns outputs and workspaces;
+ *   - return value: 0 on success, <0 for an argument error (DS_ERR_*), >0 = hipError_t from a launch.
+ */
+#ifndef DEPTHSYNTH_H_
+#define DEPTHSYNTH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DS_ERR_INVALID_ARG (-1)
+#define DS_ERR_UNSUPPORTED (-2)
+#define DS_ERR_WORKSPACE   (-3)
+
+#define DS_MAX_SOURCES 4        /* S per launch of the loss kernels (the reference uses S = SEQ_LEN-1 = 3) */
+#define DS_AUX_ARGMIN_MASK 0x1f /* aux byte: bits 0-4 argmin source, bits 5-7 clamp-pass flags of channels 0-2 */
+
+int ds_version(void);
+const char* ds_error_string(int code);
+
+/* ---- synthesis.py ------------------------------------------------------------------------------ */
+
+/* synthesis.construct_pose_batch (synthesis.py:6-33): vec (N,6) -> pose (N,3,4), and its autograd. */
+int ds_pose_from_vec_fwd(const float* vec, int N, float* pose, void* stream);
+int ds_pose_from_vec_bwd(const float* vec, const float* g_pose, int N, float* g_vec, void* stream);
+
+/* synthesis.reproject_from_depth (synthesis.py:83-116), batched over N (depth map, pose) pairs.
+ * pose (N,3,4), depth (N,H,W) -> coords (N,H,W,2) in pixel units. */
+int ds_reproject(const float* K, const float* Kinv, const float* pose, const float* depth, int N, int H, int W,
+                 float* coords, void* stream);
+
+/* autograd of ds_reproject: g_coords (N,H,W,2) -> g_depth (N,H,W), g_pose (N,3,4); workspace sized by
+ * ds_warp_bwd_workspace_bytes(N,H,W). */
+int ds_reproject_bwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* g_coords,
+                     int N, int H, int W, float* g_depth, float* g_pose, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* synthesis.synthesize (synthesis.py:36-54).  grid (N,H,W,2) holds pixel coords on entry and the
+ * NORMALISED coords on return (the reference mutates its argument, :50-51; normalisation uses the
+ * SOURCE dims Hs,Ws, :49).  src (N,C,Hs,Ws) -> out (N,C,H,W). */
+int ds_grid_sample_fwd(const float* src, float* grid, int N, int C, int Hs, int Ws, int H, int W, float* out,
+                       void* stream);
+
+/* autograd of synthesis.synthesize: grid_norm is the grid as ds_grid_sample_fwd left it.
+ * g_grid (N,H,W,2) is d/d(pixel coords).  g_src (N,C,Hs,Ws) may be NULL; when given it must be
+ * zero-filled by the caller (atomic accumulation). */
+int ds_grid_sample_bwd(const float* src, const float* grid_norm, const float* g_out, int N, int C, int Hs, int Ws,
+                       int H, int W, float* g_grid, float* g_src, void* stream);
+
+/* fused reproject_from_depth + synthesize (train.py:72-77): warped (N,C,H,W). */
+int ds_warp_fwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src, int N,
+                int C, int Hs, int Ws, int H, int W, float* warped, void* stream);
+
+/* workspace for ds_warp_bwd / ds_fused_bwd pose-gradient partials */
+size_t ds_warp_bwd_workspace_bytes(int N, int H, int W);
+
+/* autograd of ds_warp_fwd: g_depth (N,H,W), g_pose (N,3,4) (deterministic two-stage reduction, no
+ * atomics), g_src (N,C,Hs,Ws) optional (NULL to skip; zero-filled by the caller otherwise). */
+int ds_warp_bwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                const float* g_warped, int N, int C, int Hs, int Ws, int H, int W, float* g_depth, float* g_pose,
+                float* g_src, void* workspace, size_t workspace_bytes, void* stream);
+
+/* synthesis.synthesize_from_depths (synthesis.py:57-80): D constant-depth planes (HOST double[D], as
+ * constants.DEPTHS), one pose (3,4), src (C,Hs,Ws) -> out (D,C,H,W). */
+int ds_synthesize_from_depths(const float* K, const float* Kinv, const float* pose, const double* depths_host, int D,
+                              const float* src, int C, int Hs, int Ws, int H, int W, float* out, void* stream);
+
+/* synthesis.depth_from_costs (synthesis.py:119-138): cost (N,D,H,W) -> depth (N,1,H,W). */
+int ds_depth_from_costs(const float* cost, int N, int D, int H, int W, int sid, float* depth, void* stream);
+
+/* fused synthesize_from_depths + metrics.cost_volumes + depth_from_costs (train.py:49-59) for NS
+ * sources of one target: pose (NS,3,4), src (NS,C,Hs,Ws), target_small (C,H,W) -> depth (NS,1,H,W).
+ * The (D,C,H,W) images and the (NS,D,H,W) cost volume are never materialised.  D <= 128. */
+int ds_plane_sweep_depth(const float* K, const float* Kinv, const float* pose, const double* depths_host, int D,
+                         const float* src, const float* target_small, int NS, int C, int Hs, int Ws, int H, int W,
+                         int sid, float* depth, void* stream);
+
+/* ---- metrics.py -------------------------------------------------------------------------------- */
+
+/* metrics.cost_volumes (metrics.py:5-18): target (C,H,W), synth (D,C,H,W) -> cost (D,H,W). */
+int ds_cost_volume(const float* target, const float* synth, int D, int C, int H, int W, float* cost, void* stream);
+
+/* metrics.reprojection_error (metrics.py:21-51): nplanes = N*C planes of (H,W). */
+int ds_ssim_fwd(const float* preds, const float* targets, int nplanes, int H, int W, float* out, void* stream);
+/* its autograd w.r.t. preds (targets carry no gradient anywhere in the reference's callers). */
+int ds_ssim_bwd(const float* preds, const float* targets, const float* g_out, int nplanes, int H, int W,
+                float* g_preds, void* stream);
+
+/* metrics.reprojection_loss (metrics.py:54-72), batched: preds (B,S,3,H,W); targets addressed as
+ * targets + b*tgt_stride_b + s*tgt_stride_s (elements; stride_s = 0 for train.py:80's stacked target).
+ * out (B,H,W) = min over S (first index on ties); aux (B,H,W) uint8 (see DS_AUX_ARGMIN_MASK). */
+int ds_reprojection_loss_fwd(const float* preds, const float* targets, long long tgt_stride_b, long long tgt_stride_s,
+                             int B, int S, int H, int W, float* out, uint8_t* aux, void* stream);
+/* autograd w.r.t. preds: g_out (B,H,W) -> g_preds (B,S,3,H,W) (every element written). */
+int ds_reprojection_loss_bwd(const float* preds, const float* targets, long long tgt_stride_b, long long tgt_stride_s,
+                             const float* g_out, const uint8_t* aux, int B, int S, int H, int W, float* g_preds,
+                             void* stream);
+
+/* loss assembly of train.py:80-92 for B targets with S sources each: warped, src (B,S,3,H,W),
+ * target (B,3,H,W) -> out_loss, idt_loss (B,H,W), aux (B,H,W) u8, sums (B,2) fp32:
+ * sums[b][0] = mean(out/exp(idt+1e-6)) (train.py:88), sums[b][1] = mean(out) (train.py:92). */
+size_t ds_fused_loss_workspace_bytes(int B, int H, int W);
+int ds_fused_loss_fwd(const float* warped, const float* src, const float* target, int B, int S, int H, int W,
+                      float* out_loss, float* idt_loss, uint8_t* aux, float* sums, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* autograd of sums[b][0] w.r.t. warped: g_sums (B) = d(loss)/d(sums[b][0]) -> g_warped (B,S,3,H,W). */
+int ds_fused_loss_bwd(const float* warped, const float* target, const float* idt_loss, const uint8_t* aux,
+                      const float* g_sums, int B, int S, int H, int W, float* g_warped, void* stream);
+
+/* metrics.regularization_term (metrics.py:75-97): depths (N,1,H,W), targets (N,C,H,W) -> value (1)
+ * fp32 on device; workspace from ds_smooth_workspace_bytes. */
+size_t ds_smooth_workspace_bytes(int N, int H, int W);
+int ds_smooth_fwd(const float* depths, const float* targets, int N, int C, int H, int W, float* value,
+                  void* workspace, size_t workspace_bytes, void* stream);
+/* g_value (1, device) -> g_depths (N,1,H,W) */
+int ds_smooth_bwd(const float* depths, const float* targets, const float* g_value, int N, int C, int H, int W,
+                  float* g_depths, void* stream);
+
+/* metrics.rmse / rmsle / abs_rel / sq_rel (metrics.py:100-153; test.py:78-81) in ONE pass over
+ * pred, gt (B,1,H,W): out (8) fp32 = rmse, rmsle, abs_rel, sq_rel, delta<1.25, <1.25^2, <1.25^3 (not in
+ * the reference: same all-pixel denominator, parity unpinned), number of valid pixels. */
+size_t ds_metrics_workspace_bytes(int B, int H, int W);
+int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, float* out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEPTHSYNTH_H_ */
