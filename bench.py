@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- fused reprojection-loss forward+backward on N MI355X GPUs (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--image-grad] [--no-cpu]
+
+A "step" is one pass of the hot path (train.py:72-92 batched: warp fwd -> SSIM+L1/min/auto-mask fwd ->
+its backward -> warp backward with depth and pose gradients) over one synthetic batch that is already
+resident in HBM.  Kernels are called through the C ABI (include/depthsynth.h) with pre-allocated outputs.
+The batch is sharded over ranks with no data-path collective (weak scaling: every rank owns B targets);
+the only cross-rank traffic is the barrier and a MAX all-reduce of the elapsed time.
+
+Rank 0 prints ONE JSON line.  `value` = warped pixels (B*S*H*W per rank, all ranks) per second.
+`roofline` is for the dominant kernel (HIP events on the launch stream, inside this run).
+`cpu_baseline` = the CPU oracle (a scalar C port of the reference's arithmetic) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json metric: "fwd+bwd reproj loss @192x640" on the config-2/3 batch
+    "b12_s2_192x640_fwdbwd": dict(B=12, S=2, H=192, W=640, scales=1),
+    # config 3: the same over a 4-scale pyramid (each scale an independent call, K rows scaled per scale)
+    "b12_s2_192x640_pyramid4_fwdbwd": dict(B=12, S=2, H=192, W=640, scales=4),
+    # config 4: the HBM-resident-set-exceeds-cache case
+    "b64_s2_320x1024_fwdbwd": dict(B=64, S=2, H=320, W=1024, scales=1),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+
+
+class Scale:
+    """All device buffers of one (B,S,H,W) problem + the four C-ABI calls of a step."""
+
+    def __init__(self, de, B, S, H, W, dev, seed, image_grad):
+        from depth_estimation_amd import _lib as L
+        self.L, self.lib = L, L.lib()
+        self.B, self.S, self.H, self.W, self.N = B, S, H, W, B * S
+        g = torch.Generator().manual_seed(seed)
+        f = dict(dtype=torch.float32, device=dev)
+        self.src = torch.rand(B, S, 3, H, W, generator=g).to(dev)
+        self.tgt = torch.rand(B, 3, H, W, generator=g).to(dev)
+        self.depth = (1 + 79 * torch.rand(B, S, H, W, generator=g)).to(dev)
+        vec = (0.01 * torch.randn(B * S, 6, generator=g)).to(dev)
+        self.pose = de.ops.pose_from_vec(vec).contiguous()
+        K, Kinv = de.fused.intrinsics(W, H)
+        self.K, self.Kinv = K.to(dev), Kinv.to(dev)
+        self.warped = torch.empty(B, S, 3, H, W, **f)
+        self.out = torch.empty(B, H, W, **f)
+        self.idt = torch.empty(B, H, W, **f)
+        self.aux = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
+        self.sums = torch.empty(B, 2, **f)
+        self.g_sums = torch.ones(B, **f)
+        self.g_warped = torch.empty(B, S, 3, H, W, **f)
+        self.g_depth = torch.empty(B, S, H, W, **f)
+        self.g_pose = torch.empty(B, S, 3, 4, **f)
+        self.g_src = torch.zeros(B, S, 3, H, W, **f) if image_grad else None
+        self.ws_loss_n = self.lib.ds_fused_loss_workspace_bytes(B, H, W)
+        self.ws_warp_n = self.lib.ds_warp_bwd_workspace_bytes(self.N, H, W)
+        self.ws_loss = torch.empty(self.ws_loss_n, dtype=torch.uint8, device=dev)
+        self.ws_warp = torch.empty(self.ws_warp_n, dtype=torch.uint8, device=dev)
+        p = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+        lib, N = self.lib, self.N
+        self.calls = {
+            "warp_fwd": lambda st: lib.ds_warp_fwd(p(self.K), p(self.Kinv), p(self.pose), p(self.depth), p(self.src), N, 3,
+                                                    H, W, H, W, p(self.warped), st),
+            "loss_fwd": lambda st: lib.ds_fused_loss_fwd(p(self.warped), p(self.src), p(self.tgt), B, S, H, W, p(self.out),
+                                                         p(self.idt), p(self.aux), p(self.sums), p(self.ws_loss),
+                                                         self.ws_loss_n, st),
+            "loss_bwd": lambda st: lib.ds_fused_loss_bwd(p(self.warped), p(self.tgt), p(self.idt), p(self.aux),
+                                                         p(self.g_sums), B, S, H, W, p(self.g_warped), st),
+            "warp_bwd": lambda st: lib.ds_warp_bwd(p(self.K), p(self.Kinv), p(self.pose), p(self.depth), p(self.src),
+                                                   p(self.g_warped), N, 3, H, W, H, W, p(self.g_depth), p(self.g_pose),
+                                                   p(self.g_src), p(self.ws_warp), self.ws_warp_n, st),
+        }
+        # algorithmic HBM bytes of each call: every input read once, every output written once
+        px, tp = self.N * H * W, B * H * W
+        self.alg_bytes = {
+            "warp_fwd": px * (4 + 12 + 12),                       # depth + src (gather) -> warped
+            "loss_fwd": px * (12 + 12) + tp * (12 + 4 + 4 + 1),   # warped + src + target -> out, idt, aux
+            "loss_bwd": px * (12 + 12) + tp * (12 + 4 + 1),       # warped + target + idt + aux -> g_warped
+            "warp_bwd": px * (4 + 12 + 12 + 4 + (12 if image_grad else 0)),  # depth + src + g_warped -> g_depth [+ g_src]
+        }
+
+    def step(self, st):
+        if self.g_src is not None:
+            self.g_src.zero_()
+        for name in ("warp_fwd", "loss_fwd", "loss_bwd", "warp_bwd"):
+            rc = self.calls[name](st)
+            if rc != 0:
+                self.L.check(rc, name)
+
+
+def build_problem(de, wl, dev, rank, image_grad):
+    scales = []
+    for i in range(wl["scales"]):
+        scales.append(Scale(de, wl["B"], wl["S"], wl["H"] >> i, wl["W"] >> i, dev, 1000 * rank + i, image_grad))
+    return scales
+
+
+def cpu_baseline(wl, budget_s=12.0):
+    """The CPU oracle (scalar C port, 1 thread) on whole samples of the same workload, ~budget_s seconds."""
+    import numpy as np
+    from oracle import ds_oracle as o
+    o.build()
+    o.set_threads(1)
+    S, H, W = wl["S"], wl["H"], wl["W"]
+    rng = np.random.default_rng(0)
+    src = rng.random((S, 3, H, W), dtype=np.float32)
+    tgt = rng.random((3, H, W), dtype=np.float32)
+    depth = (1 + 79 * rng.random((S, H, W), dtype=np.float32)).astype(np.float32)
+    pose = o.pose_from_vec((0.01 * rng.standard_normal((S, 6))).astype(np.float32))
+    import torch as _t
+    from depth_estimation_amd.fused import intrinsics
+    K, Kinv = [a.numpy() for a in intrinsics(W, H)]
+
+    def one_sample():
+        warped = np.stack([o.warp(K, Kinv, pose[s], depth[s], src[s], H, W) for s in range(S)])
+        la = o.loss_assembly(warped, src, tgt)
+        gw = o.loss_assembly_bwd(warped, tgt, la["idt_loss"], la["argmin"])
+        for s in range(S):
+            o.warp_bwd(K, Kinv, pose[s], depth[s], src[s], gw[s], H, W, False)
+
+    one_sample()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        one_sample()
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n * S * H * W / dt / 1e9, unit="Gpix/s", cores=1, kind="port",
+                sample=f"{n} samples (1 target x {S} sources, {H}x{W}, single scale) fwd+bwd in {dt:.1f} s, "
+                       f"oracle/ds_oracle.c single thread; host has {os.cpu_count()} logical CPUs")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="b12_s2_192x640_fwdbwd", choices=sorted(WORKLOADS))
+    ap.add_argument("--image-grad", action="store_true", help="also scatter the source-image gradient")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import depth_estimation_amd as de
+    wl = WORKLOADS[args.workload]
+    scales = build_problem(de, wl, dev, rank, args.image_grad)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        for sc in scales:
+            sc.step(st)
+
+    graph = None
+    if args.graph:
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            st_side = side.cuda_stream
+            for sc in scales:
+                sc.step(st_side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for sc in scales:
+                    sc.step(torch.cuda.current_stream().cuda_stream)
+        run = graph.replay
+    else:
+        run = step
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    warped_px_rank = sum(sc.N * sc.H * sc.W for sc in scales)
+    value = world * warped_px_rank * args.steps / elapsed / 1e9
+
+    # per-kernel durations: HIP events on the launch stream around each call, inside the same step sequence
+    names = ("warp_fwd", "loss_fwd", "loss_bwd", "warp_bwd")
+    sc0 = scales[0]
+    ev = {n: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+          for n in names}
+    torch.cuda.synchronize()
+    for i in range(args.steps):
+        for sc in scales:
+            if sc is sc0:
+                for n in names:
+                    ev[n][i][0].record()
+                    sc.calls[n](st)
+                    ev[n][i][1].record()
+            else:
+                sc.step(st)
+    torch.cuda.synchronize()
+    kern_ms = {n: sum(a.elapsed_time(b) for a, b in ev[n]) / args.steps for n in names}
+    dom = max(names, key=lambda n: kern_ms[n])
+    achieved = sc0.alg_bytes[dom] / (kern_ms[dom] * 1e-3) / 1e9
+    step_bytes = sum(sum(sc.alg_bytes.values()) for sc in scales)
+
+    if rank == 0:
+        line = {
+            "metric": "warped px/s (Gpix/s) fwd+bwd reproj loss @192x640, % HBM roofline, 1-8 GPU",
+            "value": round(value, 4), "unit": "Gpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "targets_per_gpu": wl["B"], "sources_per_target": wl["S"],
+                       "height": wl["H"], "width": wl["W"], "scales": wl["scales"], "image_grad": bool(args.image_grad),
+                       "launch": "hipgraph" if args.graph else "eager", "parallelism": f"batch-sharded x{world}, no collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "alg_bytes_per_launch": sc0.alg_bytes[dom], "avg_ms": round(kern_ms[dom], 5)},
+            "kernels_ms": {n: round(kern_ms[n], 5) for n in names},
+            "step_alg_GBps": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
+            "step_frac_of_hbm_peak": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+        }
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
