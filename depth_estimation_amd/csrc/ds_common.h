@@ -35,16 +35,88 @@ __device__ __forceinline__ int lane_right_i(int v) {
     return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);
 }
 
-// Makes a register value opaque to the optimiser (no instruction is emitted).  The rolling kernels call
-// it on their row registers at the top of every row step: without it the compiler CSEs the DPP-shifted
-// copies of a row across the three steps that use it (3 live registers per row value instead of one,
-// and the shifts stay separate v_mov_dpp instead of folding into the adds).
-__device__ __forceinline__ void opaque(float& v) { asm volatile("" : "+v"(v)); }
+// ---------------------------------------------------------------------------------------------
+// 3x3 window sums of the rolling-wave kernels.
+//
+// t, m, b are one lane's values of three consecutive rows; the left/right neighbours are the adjacent
+// lanes, read through DPP wave shifts folded into the adds (v_add_f32_dpp).  The sum is sequential and
+// row-major -- ((((((((L(t)+t)+R(t))+L(m))+m)+R(m))+L(b))+b)+R(b)) -- which is the rounding order of torch's
+// avg_pool2d (the leading 0+ is exact).  Written as asm blocks because hipcc only folds a DPP move into
+// its consumer when the two end up within 20 instructions of each other, which it does not arrange in
+// kernels of this size (the un-folded form costs +40 % instructions and 3x the registers).
+//
+// Hazard bookkeeping (the compiler pads nothing inside an asm statement): a DPP operand must have been
+// written at least 2 VALU instructions earlier.  Every block therefore opens with its v_mul products
+// (>= 3 non-DPP instructions), and reads its own products through DPP no earlier than 3 instructions
+// after writing them.  All 64 lanes are active wherever these are used.
+// ---------------------------------------------------------------------------------------------
+#define DS_DPP_L " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define DS_DPP_R " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define DS_W0(acc, v) "v_add_f32_dpp " acc ", " v ", " v DS_DPP_L      /* L(v) + v      */
+#define DS_WL(acc, v) "v_add_f32_dpp " acc ", " v ", " acc DS_DPP_L    /* acc += L(v)   */
+#define DS_WR(acc, v) "v_add_f32_dpp " acc ", " v ", " acc DS_DPP_R    /* acc += R(v)   */
+#define DS_WC(acc, v) "v_add_f32 " acc ", " v ", " acc "\n\t"         /* acc += v      */
 
-// Ties the (future) DPP source v to the running sum acc: no instruction, but the shift of v can no longer
-// be scheduled ahead of acc.  LLVM's DPP combiner only folds a v_mov_dpp into its consumer when the two
-// are within 20 instructions; un-tied, all shifts of a row step are hoisted to its top and stay v_movs.
-__device__ __forceinline__ void tie(float& acc, float& v) { asm("" : "+v"(acc), "+v"(v)); }
+// target statistics: ay = win(y), ayy = win(y*y)
+__device__ __forceinline__ void win_target(float yt, float ym, float yb, float& ay, float& ayy) {
+    float p0, p1, p2;
+    asm volatile(
+        "v_mul_f32 %[p0], %[yt], %[yt]\n\t"
+        "v_mul_f32 %[p1], %[ym], %[ym]\n\t"
+        "v_mul_f32 %[p2], %[yb], %[yb]\n\t"
+        DS_W0("%[ay]", "%[yt]") DS_W0("%[ayy]", "%[p0]")
+        DS_WR("%[ay]", "%[yt]") DS_WR("%[ayy]", "%[p0]")
+        DS_WL("%[ay]", "%[ym]") DS_WL("%[ayy]", "%[p1]")
+        DS_WC("%[ay]", "%[ym]") DS_WC("%[ayy]", "%[p1]")
+        DS_WR("%[ay]", "%[ym]") DS_WR("%[ayy]", "%[p1]")
+        DS_WL("%[ay]", "%[yb]") DS_WL("%[ayy]", "%[p2]")
+        DS_WC("%[ay]", "%[yb]") DS_WC("%[ayy]", "%[p2]")
+        DS_WR("%[ay]", "%[yb]") DS_WR("%[ayy]", "%[p2]")
+        : [ay] "=&v"(ay), [ayy] "=&v"(ayy), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2)
+        : [yt] "v"(yt), [ym] "v"(ym), [yb] "v"(yb));
+}
+
+// image-pair statistics: ax = win(x), axx = win(x*x), axy = win(x*y)
+__device__ __forceinline__ void win_pair(float xt, float xm, float xb, float yt, float ym, float yb, float& ax, float& axx,
+                                         float& axy) {
+    float p0, p1, p2, q0, q1, q2;
+    asm volatile(
+        "v_mul_f32 %[p0], %[xt], %[xt]\n\t"
+        "v_mul_f32 %[q0], %[xt], %[yt]\n\t"
+        "v_mul_f32 %[p1], %[xm], %[xm]\n\t"
+        "v_mul_f32 %[q1], %[xm], %[ym]\n\t"
+        "v_mul_f32 %[p2], %[xb], %[xb]\n\t"
+        "v_mul_f32 %[q2], %[xb], %[yb]\n\t"
+        DS_W0("%[ax]", "%[xt]") DS_W0("%[axx]", "%[p0]") DS_W0("%[axy]", "%[q0]")
+        DS_WR("%[ax]", "%[xt]") DS_WR("%[axx]", "%[p0]") DS_WR("%[axy]", "%[q0]")
+        DS_WL("%[ax]", "%[xm]") DS_WL("%[axx]", "%[p1]") DS_WL("%[axy]", "%[q1]")
+        DS_WC("%[ax]", "%[xm]") DS_WC("%[axx]", "%[p1]") DS_WC("%[axy]", "%[q1]")
+        DS_WR("%[ax]", "%[xm]") DS_WR("%[axx]", "%[p1]") DS_WR("%[axy]", "%[q1]")
+        DS_WL("%[ax]", "%[xb]") DS_WL("%[axx]", "%[p2]") DS_WL("%[axy]", "%[q2]")
+        DS_WC("%[ax]", "%[xb]") DS_WC("%[axx]", "%[p2]") DS_WC("%[axy]", "%[q2]")
+        DS_WR("%[ax]", "%[xb]") DS_WR("%[axx]", "%[p2]") DS_WR("%[axy]", "%[q2]")
+        : [ax] "=&v"(ax), [axx] "=&v"(axx), [axy] "=&v"(axy), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2),
+          [q0] "=&v"(q0), [q1] "=&v"(q1), [q2] "=&v"(q2)
+        : [xt] "v"(xt), [xm] "v"(xm), [xb] "v"(xb), [yt] "v"(yt), [ym] "v"(ym), [yb] "v"(yb));
+}
+
+// h = v + wL * (lane-1's v) + wR * (lane+1's v) for three values at once: the horizontal spread of the
+// backward kernels (wL, wR are 1, or 2 where the reflect padding folds a border window back).  The three
+// moves in front keep every DPP source at least 2 VALU instructions old.
+__device__ __forceinline__ void spread3(float a, float b, float c, float wL, float wR, float& ha, float& hb, float& hc) {
+    asm volatile(
+        "v_mov_b32 %[ha], %[a]\n\t"
+        "v_mov_b32 %[hb], %[b]\n\t"
+        "v_mov_b32 %[hc], %[c]\n\t"
+        "v_fmac_f32_dpp %[ha], %[a], %[wL]" DS_DPP_L
+        "v_fmac_f32_dpp %[hb], %[b], %[wL]" DS_DPP_L
+        "v_fmac_f32_dpp %[hc], %[c], %[wL]" DS_DPP_L
+        "v_fmac_f32_dpp %[ha], %[a], %[wR]" DS_DPP_R
+        "v_fmac_f32_dpp %[hb], %[b], %[wR]" DS_DPP_R
+        "v_fmac_f32_dpp %[hc], %[c], %[wR]" DS_DPP_R
+        : [ha] "=&v"(ha), [hb] "=&v"(hb), [hc] "=&v"(hc)
+        : [a] "v"(a), [b] "v"(b), [c] "v"(c), [wL] "v"(wL), [wR] "v"(wR));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -23,34 +23,6 @@ namespace {
 
 constexpr int kWaves = 4;  // wavefronts per block (independent of each other)
 
-// sequential 3x3 window sum over three rolling rows; T,M,B = slots of rows r-1, r, r+1
-template <int T, int M, int B>
-__device__ __forceinline__ float win9(const float (&a)[3]) {
-    float t = a[T], m = a[M], b = a[B];
-    float acc = lane_left(t) + t;
-    tie(acc, t);
-    acc = acc + lane_right(t);
-    tie(acc, m);
-    acc = acc + lane_left(m);
-    acc = acc + m;
-    tie(acc, m);
-    acc = acc + lane_right(m);
-    tie(acc, b);
-    acc = acc + lane_left(b);
-    acc = acc + b;
-    tie(acc, b);
-    acc = acc + lane_right(b);
-    return acc;
-}
-
-// same sum over the products a*b of two rolling planes (x*x, y*y, x*y of metrics.py:41-43): the three
-// per-row products are formed once per lane, their neighbours again come through DPP
-template <int T, int M, int B>
-__device__ __forceinline__ float win9p(const float (&a)[3], const float (&b)[3]) {
-    const float p[3] = {a[T] * b[T], a[M] * b[M], a[B] * b[B]};
-    return win9<0, 1, 2>(p);
-}
-
 struct BandGeom {
     int b, y0, yend, col, cl, lane;
     bool active;
@@ -118,20 +90,17 @@ __device__ __forceinline__ void fwd_window(FwdState<S, IDT>& st, float (&E)[FwdS
     for (int g = 0; g < G; ++g) pass[g] = 0u;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            opaque(st.Y[c][k]);
-#pragma unroll
-            for (int g = 0; g < G; ++g) opaque(st.X[g][c][k]);
-        }
+        float ay, ayy;
+        win_target(st.Y[c][T], st.Y[c][M], st.Y[c][Bt], ay, ayy);
         TgtStats ts;
-        target_stats(win9<T, M, Bt>(st.Y[c]), win9p<T, M, Bt>(st.Y[c], st.Y[c]), ts);
+        target_stats(ay, ayy, ts);
         const float yc = st.Y[c][M];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+            float ax, axx, axy;
+            win_pair(st.X[g][c][T], st.X[g][c][M], st.X[g][c][Bt], st.Y[c][T], st.Y[c][M], st.Y[c][Bt], ax, axx, axy);
             SsimOut so;
-            ssim_from_sums(win9<T, M, Bt>(st.X[g][c]), win9p<T, M, Bt>(st.X[g][c], st.X[g][c]),
-                           win9p<T, M, Bt>(st.X[g][c], st.Y[c]), ts, so);
+            ssim_from_sums(ax, axx, axy, ts, so);
             const float e = 0.85f * clamp01(so.v) + 0.15f * fabsf(yc - st.X[g][c][M]);
             E[g] = (c == 0) ? e : E[g] + e;
             pass[g] |= (so.v >= 0.0f && so.v <= 1.0f) ? (1u << c) : 0u;
@@ -265,14 +234,16 @@ __global__ __launch_bounds__(64 * kWaves) void ssim_fwd_kernel(const float* __re
     const float* xp = preds + (size_t)g.b * HW + g.cl;
     const float* yp = targets + (size_t)g.b * HW + g.cl;
     const bool lane_out = g.lane >= 1 && g.lane <= 62 && g.col < W;
-    float X[3], XX[3], XY[3], Y[3], YY[3];
-    auto place = [&](int slot, int r) {
+    float X[3], Y[3];
+    auto place = [&](int slot, int r) {  // slot is a compile-time constant at every call site after unrolling
         const size_t ro = (size_t)reflect_idx(r, H) * W;
-        float x = xp[ro], y = yp[ro];
-        // slot is a compile-time constant at every call site after unrolling
-        X[slot] = x; Y[slot] = y; XX[slot] = x * x; YY[slot] = y * y; XY[slot] = x * y;
+        X[slot] = xp[ro];
+        Y[slot] = yp[ro];
     };
-    auto emit = [&](int y, float ax, float ay, float axx, float ayy, float axy) {
+    auto emit = [&](int y, int T, int M, int Bt) {
+        float ax, axx, axy, ay, ayy;
+        win_target(Y[T], Y[M], Y[Bt], ay, ayy);
+        win_pair(X[T], X[M], X[Bt], Y[T], Y[M], Y[Bt], ax, axx, axy);
         TgtStats ts;
         target_stats(ay, ayy, ts);
         SsimOut so;
@@ -283,13 +254,13 @@ __global__ __launch_bounds__(64 * kWaves) void ssim_fwd_kernel(const float* __re
     place(1, g.y0);
     for (int y = g.y0; y < g.yend; y += 3) {
         place(2, y + 1);
-        emit(y, win9<0, 1, 2>(X), win9<0, 1, 2>(Y), win9<0, 1, 2>(XX), win9<0, 1, 2>(YY), win9<0, 1, 2>(XY));
+        emit(y, 0, 1, 2);
         if (y + 1 >= g.yend) break;
         place(0, y + 2);
-        emit(y + 1, win9<1, 2, 0>(X), win9<1, 2, 0>(Y), win9<1, 2, 0>(XX), win9<1, 2, 0>(YY), win9<1, 2, 0>(XY));
+        emit(y + 1, 1, 2, 0);
         if (y + 2 >= g.yend) break;
         place(1, y + 3);
-        emit(y + 2, win9<2, 0, 1>(X), win9<2, 0, 1>(Y), win9<2, 0, 1>(XX), win9<2, 0, 1>(YY), win9<2, 0, 1>(XY));
+        emit(y + 2, 2, 0, 1);
     }
 }
 
@@ -364,19 +335,21 @@ __device__ __forceinline__ void bwd_window(BwdState<S>& st, bool win_exists, int
     const float ge = win_exists ? st.GW[M] * (1.0f / 3.0f) : 0.0f;  // d loss / d e_c of this window
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
+        float ay, ayy;
+        win_target(st.Y[c][T], st.Y[c][M], st.Y[c][Bt], ay, ayy);
         TgtStats ts;
-        target_stats(win9<T, M, Bt>(st.Y[c]), win9p<T, M, Bt>(st.Y[c], st.Y[c]), ts);
+        target_stats(ay, ayy, ts);
         const float gv_c = ((passbits >> c) & 1) ? 0.85f * ge : 0.0f;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
+            float ax, axx, axy;
+            win_pair(st.X[s][c][T], st.X[s][c][M], st.X[s][c][Bt], st.Y[c][T], st.Y[c][M], st.Y[c][Bt], ax, axx, axy);
             SsimOut so;
-            ssim_from_sums(win9<T, M, Bt>(st.X[s][c]), win9p<T, M, Bt>(st.X[s][c], st.X[s][c]),
-                           win9p<T, M, Bt>(st.X[s][c], st.Y[c]), ts, so);
+            ssim_from_sums(ax, axx, axy, ts, so);
             const float gv = (am == s + s_offset) ? gv_c : 0.0f;
             const Coef k = ssim_coefs(so, ts, gv);
-            const float hA = fmaf(wL, lane_left(k.A), fmaf(wR, lane_right(k.A), k.A));
-            const float hB = fmaf(wL, lane_left(k.Bc), fmaf(wR, lane_right(k.Bc), k.Bc));
-            const float hC = fmaf(wL, lane_left(k.Cc), fmaf(wR, lane_right(k.Cc), k.Cc));
+            float hA, hB, hC;
+            spread3(k.A, k.Bc, k.Cc, wL, wR, hA, hB, hC);
             st.ACC[Bt][s][c][0] = wU_next * hA;
             st.ACC[Bt][s][c][1] = wU_next * hB;
             st.ACC[Bt][s][c][2] = wU_next * hC;
@@ -507,24 +480,25 @@ __global__ __launch_bounds__(64 * kWaves) void ssim_bwd_kernel(const float* __re
     const bool col_exists = g.col >= 0 && g.col < W;
     const bool lane_out = g.lane >= 2 && g.lane <= 61 && g.col < W;
     const float wL = g.col == 1 ? 2.0f : 1.0f, wR = g.col == W - 2 ? 2.0f : 1.0f;
-    float X[3], XX[3], XY[3], Y[3], YY[3], GW[3], ACC[3][3];
+    float X[3], Y[3], GW[3], ACC[3][3];
     auto place = [&](int slot, int r) {
         const size_t ro = (size_t)reflect_idx(r, H) * W;
-        float x = xp[ro], y = yp[ro];
-        X[slot] = x; Y[slot] = y; XX[slot] = x * x; YY[slot] = y * y; XY[slot] = x * y;
+        X[slot] = xp[ro];
+        Y[slot] = yp[ro];
         GW[slot] = wp[ro];
     };
-    auto window = [&](int T, int M, int Bt, bool exists, float ax, float ay, float axx, float ayy, float axy, float wUn,
-                      float wDp) {
+    auto window = [&](int T, int M, int Bt, bool exists, float wUn, float wDp) {
+        float ax, axx, axy, ay, ayy;
+        win_target(Y[T], Y[M], Y[Bt], ay, ayy);
+        win_pair(X[T], X[M], X[Bt], Y[T], Y[M], Y[Bt], ax, axx, axy);
         TgtStats ts;
         target_stats(ay, ayy, ts);
         SsimOut so;
         ssim_from_sums(ax, axx, axy, ts, so);
         const float gv = (exists && so.v >= 0.0f && so.v <= 1.0f) ? GW[M] : 0.0f;
         const Coef k = ssim_coefs(so, ts, gv);
-        const float h[3] = {fmaf(wL, lane_left(k.A), fmaf(wR, lane_right(k.A), k.A)),
-                            fmaf(wL, lane_left(k.Bc), fmaf(wR, lane_right(k.Bc), k.Bc)),
-                            fmaf(wL, lane_left(k.Cc), fmaf(wR, lane_right(k.Cc), k.Cc))};
+        float h[3];
+        spread3(k.A, k.Bc, k.Cc, wL, wR, h[0], h[1], h[2]);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             ACC[Bt][i] = wUn * h[i];
@@ -544,18 +518,15 @@ __global__ __launch_bounds__(64 * kWaves) void ssim_bwd_kernel(const float* __re
     const int rlast = g.yend + 1;
     for (int r = g.y0; r <= rlast; r += 3) {
         place(2, r);
-        window(0, 1, 2, col_exists && r - 1 >= 0 && r - 1 < H, win9<0, 1, 2>(X), win9<0, 1, 2>(Y), win9<0, 1, 2>(XX),
-               win9<0, 1, 2>(YY), win9<0, 1, 2>(XY), wU(r), wD(r - 2));
+        window(0, 1, 2, col_exists && r - 1 >= 0 && r - 1 < H, wU(r), wD(r - 2));
         if (r - 2 >= g.y0) emit(r - 2, 0);
         if (r + 1 > rlast) break;
         place(0, r + 1);
-        window(1, 2, 0, col_exists && r >= 0 && r < H, win9<1, 2, 0>(X), win9<1, 2, 0>(Y), win9<1, 2, 0>(XX),
-               win9<1, 2, 0>(YY), win9<1, 2, 0>(XY), wU(r + 1), wD(r - 1));
+        window(1, 2, 0, col_exists && r >= 0 && r < H, wU(r + 1), wD(r - 1));
         if (r - 1 >= g.y0) emit(r - 1, 1);
         if (r + 2 > rlast) break;
         place(1, r + 2);
-        window(2, 0, 1, col_exists && r + 1 >= 0 && r + 1 < H, win9<2, 0, 1>(X), win9<2, 0, 1>(Y), win9<2, 0, 1>(XX),
-               win9<2, 0, 1>(YY), win9<2, 0, 1>(XY), wU(r + 2), wD(r));
+        window(2, 0, 1, col_exists && r + 1 >= 0 && r + 1 < H, wU(r + 2), wD(r));
         emit(r, 2);
     }
 }

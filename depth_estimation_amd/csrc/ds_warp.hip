@@ -342,11 +342,24 @@ __global__ void pose_from_vec_bwd_kernel(const float* __restrict__ vec, const fl
 
 // partials (N, nblk, 12) -> g_pose (N,12): fixed summation order, double accumulator
 __global__ void pose_finalize_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ g_pose) {
-    const int n = blockIdx.x, i = threadIdx.x;
-    if (i >= 12) return;
-    double a = 0.0;
-    for (int b = 0; b < nblk; ++b) a += (double)partials[((size_t)n * nblk + b) * 12 + i];
-    g_pose[n * 12 + i] = (float)a;
+    const int n = blockIdx.x, lane = threadIdx.x;  // one 64-lane wave per pose
+    double a[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) a[i] = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+        const float* q = partials + ((size_t)n * nblk + b) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) a[i] += (double)q[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a[i] += __shfl_xor(a[i], o, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) g_pose[n * 12 + i] = (float)a[i];
+    }
 }
 
 inline int pix_blocks(int HW) { return (HW + kThreads - 1) / kThreads; }
