@@ -118,6 +118,22 @@ __device__ __forceinline__ void spread3(float a, float b, float c, float wL, flo
         : [a] "v"(a), [b] "v"(b), [c] "v"(c), [wL] "v"(wL), [wR] "v"(wR));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row loads of the rolling kernels: buffer_load with the image base in an SGPR descriptor, the wave-uniform
+// plane/row offset in an SGPR (soffset) and the lane's column offset in one VGPR -- no per-load VALU address
+// arithmetic.  Offsets are 32-bit: one descriptor per image, whose planes must span < 4 GiB (checked on the host).
+// ---------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float buf_load_f32(rsrc_t r, unsigned lane_bytes, unsigned uniform_elems) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_bytes, uniform_elems * 4u, 0));
+}
+__device__ __forceinline__ int buf_load_u8(rsrc_t r, unsigned lane_bytes, unsigned uniform_bytes) {
+    return (int)__builtin_amdgcn_raw_buffer_load_b8(r, lane_bytes, uniform_bytes, 0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -141,6 +157,22 @@ __device__ __forceinline__ float div3(float x) {
     float q = x * y;
     float r = fmaf(-q, 3.0f, x);
     return fmaf(r, y, q);
+}
+
+// n/d, correctly rounded, for operands that need no range scaling: the instruction sequence hipcc emits for an
+// IEEE f32 divide minus its v_div_scale / v_div_fixup range handling (12 -> 8 instructions).  The SSIM
+// denominator is >= C1*C2 = 9e-8 and both operands stay below ~2^40 for pixel magnitudes below 2^8, far from the
+// exponents where v_div_scale would rescale, so the result is bit-identical to the full sequence;
+// tests/test_gpu_parity.py pins it against the oracle's true divide.
+__device__ __forceinline__ float div_noscale(float n, float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = fmaf(-d, r0, 1.0f);
+    const float r1 = fmaf(e0, r0, r0);
+    const float q0 = n * r1;
+    const float e1 = fmaf(-d, q0, n);
+    const float q1 = fmaf(e1, r1, q0);
+    const float e2 = fmaf(-d, q1, n);
+    return fmaf(e2, r1, q1);
 }
 
 __device__ __forceinline__ int reflect_idx(int i, int L) {  // reflect pad 1, then clamp (lanes outside the band)
@@ -248,30 +280,36 @@ __device__ __forceinline__ void sample_setup(float u, float v, int Hs, int Ws, S
     sample_setup_norm(gx, gy, Hs, Ws, s);
 }
 
-// corner offsets/validity shared by every channel of one pixel
+// corner offsets/validity shared by every channel of one pixel.  The two texels of a corner row are adjacent in
+// memory, so each row is ONE 8-byte load (4-byte aligned; gfx950 global loads need no natural alignment): 2
+// gather instructions per channel instead of 4 -- the warp kernels are bound by gather address processing.
+// At the right border (x0 == Ws-1) the pair is shifted one texel left and the values re-assigned.
 struct Corners {
-    int o_nw, o_ne, o_sw, o_se;   // element offsets inside one (Hs,Ws) plane (clamped to a valid address)
-    bool xin, yin;                // x0+1 < Ws, y0+1 < Hs
+    int o_top, o_bot;   // element offset of the LEFT texel of the loaded pair in rows y0 / y1 (a valid address)
+    bool shift;         // x0 == Ws-1: the pair starts at x0-1, so nw/sw are its second texel and ne/se do not exist
+    bool xin, yin;      // x0+1 < Ws, y0+1 < Hs
 };
+
+struct __attribute__((packed, aligned(4))) TexelPair { float a, b; };
 
 __device__ __forceinline__ void corner_offsets(const Samp& s, int Hs, int Ws, Corners& c) {
     c.xin = s.x0 + 1 < Ws;
     c.yin = s.y0 + 1 < Hs;
-    int x1 = c.xin ? s.x0 + 1 : s.x0;
-    int y1 = c.yin ? s.y0 + 1 : s.y0;
-    c.o_nw = s.y0 * Ws + s.x0;
-    c.o_ne = s.y0 * Ws + x1;
-    c.o_sw = y1 * Ws + s.x0;
-    c.o_se = y1 * Ws + x1;
+    c.shift = !c.xin;
+    const int xc = c.xin ? s.x0 : s.x0 - 1;   // Ws >= 2 (checked on the host)
+    const int y1 = c.yin ? s.y0 + 1 : s.y0;
+    c.o_top = s.y0 * Ws + xc;
+    c.o_bot = y1 * Ws + xc;
 }
 
 __device__ __forceinline__ void gather4(const float* __restrict__ plane, const Corners& c, float& nw, float& ne,
                                         float& sw, float& se) {
-    nw = plane[c.o_nw];
-    float a = plane[c.o_ne], b = plane[c.o_sw], d = plane[c.o_se];
-    ne = c.xin ? a : 0.0f;
-    sw = c.yin ? b : 0.0f;
-    se = (c.xin && c.yin) ? d : 0.0f;
+    const TexelPair t = *reinterpret_cast<const TexelPair*>(plane + c.o_top);
+    const TexelPair b = *reinterpret_cast<const TexelPair*>(plane + c.o_bot);
+    nw = c.shift ? t.b : t.a;
+    ne = c.shift ? 0.0f : t.b;
+    sw = c.yin ? (c.shift ? b.b : b.a) : 0.0f;
+    se = (c.xin && c.yin) ? b.b : 0.0f;
 }
 
 __device__ __forceinline__ float bilinear(float nw, float ne, float sw, float se, const Samp& s) {
@@ -303,7 +341,7 @@ __device__ __forceinline__ void ssim_from_sums(float ax, float axx, float axy, c
     // (2*mx)*my == 2*(mx*my) and 2*s+C rounds once either way: the doublings are exact
     o.n = fmaf(2.0f, mxy, kC1) * fmaf(2.0f, o.sxy, kC2);
     o.dd = ((mx2 + t.my2) + kC1) * ((o.sx + t.sy_raw) + kC2);
-    o.v = (1.0f - o.n / o.dd) * 0.5f;
+    o.v = (1.0f - div_noscale(o.n, o.dd)) * 0.5f;
 }
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }

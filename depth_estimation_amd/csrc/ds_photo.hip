@@ -14,8 +14,12 @@
 // rounded divide: bit-identical to torch's avg_pool2d.  VALU-heavy by necessity:
 // 5 window sums x 9 taps per (pixel, channel, image pair) cannot be shared between windows without
 // changing the rounding order.
+#ifndef DS_EXP
+#define DS_EXP 0
+#endif
 #include "ds_common.h"
 #include "depthsynth.h"
+#include <math.h>
 
 using namespace ds;
 
@@ -32,7 +36,9 @@ struct BandGeom {
 template <int HALO>
 __device__ __forceinline__ BandGeom band_geom(int B, int H, int W, int nbx, int nby, int RB) {
     BandGeom g;
-    const int wave = threadIdx.x >> 6;
+    // readfirstlane: the wave index is uniform, but only this tells the compiler -- everything derived from it
+    // (image, row chunk, row offsets, loop bounds) then lives in SGPRs and the row loop branches on SCC
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     g.lane = threadIdx.x & 63;
     const int wg = xcd_remap(blockIdx.x, gridDim.x) * kWaves + wave;
     g.active = wg < B * nby * nbx;
@@ -83,27 +89,39 @@ __device__ __forceinline__ void fwd_place(FwdState<S, IDT>& st, const float (&nx
 
 // photometric error of the window centred on row MID for every group; E[g] = ((e0+e1)+e2)/3
 template <int S, bool IDT, int T, int M, int Bt>
-__device__ __forceinline__ void fwd_window(FwdState<S, IDT>& st, float (&E)[FwdState<S, IDT>::G],
-                                           unsigned (&pass)[FwdState<S, IDT>::G]) {
+__device__ __forceinline__ void fwd_window(FwdState<S, IDT>& st, float (&E)[FwdState<S, IDT>::G]) {
     constexpr int G = FwdState<S, IDT>::G;
-#pragma unroll
-    for (int g = 0; g < G; ++g) pass[g] = 0u;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float ay, ayy;
+#if DS_EXP == 2 || DS_EXP == 3
+        ay = st.Y[c][T] + st.Y[c][M]; ayy = st.Y[c][Bt];
+#else
         win_target(st.Y[c][T], st.Y[c][M], st.Y[c][Bt], ay, ayy);
+#endif
         TgtStats ts;
+#if DS_EXP == 1 || DS_EXP == 3
+        ts.my = ay; ts.my2 = ayy; ts.sy_raw = ay;
+#else
         target_stats(ay, ayy, ts);
+#endif
         const float yc = st.Y[c][M];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float ax, axx, axy;
+#if DS_EXP == 2 || DS_EXP == 3
+            ax = st.X[g][c][T]; axx = st.X[g][c][M]; axy = st.X[g][c][Bt];
+#else
             win_pair(st.X[g][c][T], st.X[g][c][M], st.X[g][c][Bt], st.Y[c][T], st.Y[c][M], st.Y[c][Bt], ax, axx, axy);
+#endif
             SsimOut so;
+#if DS_EXP == 1 || DS_EXP == 3
+            so.v = (ax + axx) + (axy + ts.my);
+#else
             ssim_from_sums(ax, axx, axy, ts, so);
+#endif
             const float e = 0.85f * clamp01(so.v) + 0.15f * fabsf(yc - st.X[g][c][M]);
             E[g] = (c == 0) ? e : E[g] + e;
-            pass[g] |= (so.v >= 0.0f && so.v <= 1.0f) ? (1u << c) : 0u;
         }
     }
 #pragma unroll
@@ -115,40 +133,53 @@ __global__ __launch_bounds__(64 * kWaves) void photo_fwd_kernel(PhotoFwdParams P
     constexpr int G = FwdState<S, IDT>::G;
     const BandGeom g = band_geom<1>(P.B, P.H, P.W, P.nbx, P.nby, P.RB);
     if (!g.active) return;
+    const unsigned cl = (unsigned)g.cl * 4u;  // lane's column byte offset: the only per-lane part of a load address
     const int H = P.H, W = P.W;
     const size_t HW = (size_t)H * W;
-    const float* tp = P.target + (size_t)g.b * P.tgt_stride_b + g.cl;
-    const float* pp = P.preds + (size_t)g.b * P.pred_stride_b + g.cl;
-    const float* sp = IDT ? P.src + (size_t)g.b * (S * 3 * HW) + g.cl : nullptr;
+    const rsrc_t tp = make_rsrc(P.target + (size_t)g.b * P.tgt_stride_b);
+    const rsrc_t pp = make_rsrc(P.preds + (size_t)g.b * P.pred_stride_b);
+    const rsrc_t sp = make_rsrc(IDT ? P.src + (size_t)g.b * (S * 3 * HW) : P.preds);
+    const unsigned uHW = (unsigned)HW;
     const bool lane_out = g.lane >= 1 && g.lane <= 62 && g.col < W;
 
     FwdState<S, IDT> st;
     float nx[G][3], ny[3];
     auto load_row = [&](int r) {
-        const size_t ro = (size_t)reflect_idx(r, H) * W;
+        const unsigned ro = (unsigned)(reflect_idx(r, H) * W);
+#if DS_EXP == 4
+        const float base = 0.3f + 0.001f * (float)(r & 7) + 0.002f * (float)g.lane;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            ny[c] = tp[c * HW + ro];
+            ny[c] = base + 0.1f * c;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                nx[s][c] = pp[(s * 3 + c) * HW + ro];
-                if (IDT) nx[S + s][c] = sp[(s * 3 + c) * HW + ro];
+                nx[s][c] = base * (1.1f + 0.1f * s) + 0.05f * c;
+                if (IDT) nx[S + s][c] = base * (0.9f - 0.1f * s) + 0.07f * c;
             }
         }
+        (void)ro;
+#else
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ny[c] = buf_load_f32(tp, cl, c * uHW + ro);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                nx[s][c] = buf_load_f32(pp, cl, (s * 3 + c) * uHW + ro);
+                if (IDT) nx[S + s][c] = buf_load_f32(sp, cl, (s * 3 + c) * uHW + ro);
+            }
+        }
+#endif
     };
     float sum_ratio = 0.f, sum_out = 0.f;
-    auto emit = [&](int y, const float (&E)[G], const unsigned (&pass)[G]) {
+    auto emit = [&](int y, const float (&E)[G]) {
         float best = E[0];
         int bi = 0;
 #pragma unroll
         for (int s = 1; s < S; ++s)
             if (E[s] < best) { best = E[s]; bi = s; }
-        unsigned pb = pass[0];
-#pragma unroll
-        for (int s = 1; s < S; ++s) pb = (bi == s) ? pass[s] : pb;
         const size_t o = (size_t)g.b * HW + (size_t)y * W + g.col;
         if (lane_out) {
-            unsigned a = (unsigned)(bi + P.s_offset) | (pb << 5);
+            const unsigned a = (unsigned)(bi + P.s_offset);
             bool keep = true;
             if (P.s_offset > 0) keep = best < P.out[o];  // later chunk: strictly smaller wins (first index on ties)
             if (keep) {
@@ -171,25 +202,26 @@ __global__ __launch_bounds__(64 * kWaves) void photo_fwd_kernel(PhotoFwdParams P
     fwd_place<S, IDT, 0>(st, nx, ny);
     load_row(g.y0);
     fwd_place<S, IDT, 1>(st, nx, ny);
+    // the next row is always prefetched, also past the chunk's end (indices are clamped, the values unused): a
+    // conditional load would make the compiler drain vmcnt to 0 right behind it
     load_row(g.y0 + 1);
     float E[G];
-    unsigned pass[G];
     for (int y = g.y0; y < g.yend; y += 3) {
         // output row y: rows (y-1,y,y+1) in slots (0,1,2)
         fwd_place<S, IDT, 2>(st, nx, ny);
-        if (y + 1 < g.yend) load_row(y + 2);
-        fwd_window<S, IDT, 0, 1, 2>(st, E, pass);
-        emit(y, E, pass);
+        load_row(y + 2);
+        fwd_window<S, IDT, 0, 1, 2>(st, E);
+        emit(y, E);
         if (y + 1 >= g.yend) break;
         fwd_place<S, IDT, 0>(st, nx, ny);
-        if (y + 2 < g.yend) load_row(y + 3);
-        fwd_window<S, IDT, 1, 2, 0>(st, E, pass);
-        emit(y + 1, E, pass);
+        load_row(y + 3);
+        fwd_window<S, IDT, 1, 2, 0>(st, E);
+        emit(y + 1, E);
         if (y + 2 >= g.yend) break;
         fwd_place<S, IDT, 1>(st, nx, ny);
-        if (y + 3 < g.yend) load_row(y + 4);
-        fwd_window<S, IDT, 2, 0, 1>(st, E, pass);
-        emit(y + 2, E, pass);
+        load_row(y + 4);
+        fwd_window<S, IDT, 2, 0, 1>(st, E);
+        emit(y + 2, E);
     }
     if (IDT) {
         sum_ratio = wave_sum(sum_ratio);
@@ -230,15 +262,16 @@ __global__ __launch_bounds__(64 * kWaves) void ssim_fwd_kernel(const float* __re
                                                                int W, int nbx, int nby, int RB, float* __restrict__ out) {
     const BandGeom g = band_geom<1>(nplanes, H, W, nbx, nby, RB);
     if (!g.active) return;
+    const unsigned cl = (unsigned)g.cl * 4u;  // lane's column byte offset: the only per-lane part of a load address
     const size_t HW = (size_t)H * W;
-    const float* xp = preds + (size_t)g.b * HW + g.cl;
-    const float* yp = targets + (size_t)g.b * HW + g.cl;
+    const float* xp = preds + (size_t)g.b * HW;
+    const float* yp = targets + (size_t)g.b * HW;
     const bool lane_out = g.lane >= 1 && g.lane <= 62 && g.col < W;
     float X[3], Y[3];
     auto place = [&](int slot, int r) {  // slot is a compile-time constant at every call site after unrolling
         const size_t ro = (size_t)reflect_idx(r, H) * W;
-        X[slot] = xp[ro];
-        Y[slot] = yp[ro];
+        X[slot] = (xp + ro)[cl >> 2];
+        Y[slot] = (yp + ro)[cl >> 2];
     };
     auto emit = [&](int y, int T, int M, int Bt) {
         float ax, axx, axy, ay, ayy;
@@ -330,8 +363,7 @@ __device__ __forceinline__ void bwd_place(BwdState<S>& st, const float (&nx)[S][
 template <int S, int T, int M, int Bt>
 __device__ __forceinline__ void bwd_window(BwdState<S>& st, bool win_exists, int s_offset, float wL, float wR, float wU_next,
                                            float wD_prev) {
-    const int am = st.AM[M] & 0x1f;
-    const int passbits = st.AM[M] >> 5;
+    const int idx = (st.AM[M] & 0x1f) - s_offset;  // argmin source of this window, relative to this launch's first
     const float ge = win_exists ? st.GW[M] * (1.0f / 3.0f) : 0.0f;  // d loss / d e_c of this window
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -339,17 +371,31 @@ __device__ __forceinline__ void bwd_window(BwdState<S>& st, bool win_exists, int
         win_target(st.Y[c][T], st.Y[c][M], st.Y[c][Bt], ay, ayy);
         TgtStats ts;
         target_stats(ay, ayy, ts);
-        const float gv_c = ((passbits >> c) & 1) ? 0.85f * ge : 0.0f;
+        const float gv_c = 0.85f * ge;
+        // window sums of every source, then ONE SSIM + coefficient evaluation: only the argmin source of this
+        // window receives gradient, so its sums are selected per lane before the formula
+        float ax[S], axx[S], axy[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            win_pair(st.X[s][c][T], st.X[s][c][M], st.X[s][c][Bt], st.Y[c][T], st.Y[c][M], st.Y[c][Bt], ax[s], axx[s], axy[s]);
+        float bx = ax[0], bxx = axx[0], bxy = axy[0];
+#pragma unroll
+        for (int s = 1; s < S; ++s) {
+            const bool is = idx == s;
+            bx = is ? ax[s] : bx;
+            bxx = is ? axx[s] : bxx;
+            bxy = is ? axy[s] : bxy;
+        }
+        SsimOut so;
+        ssim_from_sums(bx, bxx, bxy, ts, so);
+        // clamp passes the gradient iff 0 <= v <= 1 (so.v is recomputed bit-identically to the forward)
+        const bool live = idx >= 0 && idx < S && so.v >= 0.0f && so.v <= 1.0f;
+        const Coef k = ssim_coefs(so, ts, live ? gv_c : 0.0f);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            float ax, axx, axy;
-            win_pair(st.X[s][c][T], st.X[s][c][M], st.X[s][c][Bt], st.Y[c][T], st.Y[c][M], st.Y[c][Bt], ax, axx, axy);
-            SsimOut so;
-            ssim_from_sums(ax, axx, axy, ts, so);
-            const float gv = (am == s + s_offset) ? gv_c : 0.0f;
-            const Coef k = ssim_coefs(so, ts, gv);
+            const bool is = idx == s;
             float hA, hB, hC;
-            spread3(k.A, k.Bc, k.Cc, wL, wR, hA, hB, hC);
+            spread3(is ? k.A : 0.0f, is ? k.Bc : 0.0f, is ? k.Cc : 0.0f, wL, wR, hA, hB, hC);
             st.ACC[Bt][s][c][0] = wU_next * hA;
             st.ACC[Bt][s][c][1] = wU_next * hB;
             st.ACC[Bt][s][c][2] = wU_next * hC;
@@ -367,13 +413,15 @@ template <int S, bool FUSED>
 __global__ __launch_bounds__(64 * kWaves) void photo_bwd_kernel(PhotoBwdParams P) {
     const BandGeom g = band_geom<2>(P.B, P.H, P.W, P.nbx, P.nby, P.RB);
     if (!g.active) return;
+    const unsigned cl = (unsigned)g.cl * 4u;  // lane's column byte offset: the only per-lane part of a load address
     const int H = P.H, W = P.W;
     const size_t HW = (size_t)H * W;
-    const float* tp = P.target + (size_t)g.b * P.tgt_stride_b + g.cl;
-    const float* pp = P.preds + (size_t)g.b * P.pred_stride_b + g.cl;
+    const rsrc_t tp = make_rsrc(P.target + (size_t)g.b * P.tgt_stride_b);
+    const rsrc_t pp = make_rsrc(P.preds + (size_t)g.b * P.pred_stride_b);
+    const unsigned uHW = (unsigned)HW;
     float* gp = P.g_preds + (size_t)g.b * P.pred_stride_b + g.col;
-    const float* wp = (FUSED ? P.idt : P.g_out) + (size_t)g.b * HW + g.cl;
-    const uint8_t* ap = P.aux + (size_t)g.b * HW + g.cl;
+    const rsrc_t wp = make_rsrc((FUSED ? P.idt : P.g_out) + (size_t)g.b * HW);
+    const rsrc_t ap = make_rsrc(P.aux + (size_t)g.b * HW);
     const float gscale = FUSED ? P.g_sums[g.b] * P.inv_hw : 1.0f;
     const bool col_exists = g.col >= 0 && g.col < W;
     const bool lane_out = g.lane >= 2 && g.lane <= 61 && g.col < W;
@@ -383,16 +431,16 @@ __global__ __launch_bounds__(64 * kWaves) void photo_bwd_kernel(PhotoBwdParams P
     float nx[S][3], ny[3], ngw;
     int nam;
     auto load_row = [&](int r) {
-        const size_t ro = (size_t)reflect_idx(r, H) * W;
+        const unsigned ro = (unsigned)(reflect_idx(r, H) * W);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            ny[c] = tp[c * HW + ro];
+            ny[c] = buf_load_f32(tp, cl, c * uHW + ro);
 #pragma unroll
-            for (int s = 0; s < S; ++s) nx[s][c] = pp[(s * 3 + c) * HW + ro];
+            for (int s = 0; s < S; ++s) nx[s][c] = buf_load_f32(pp, cl, (s * 3 + c) * uHW + ro);
         }
-        const float w = wp[ro];
+        const float w = buf_load_f32(wp, cl, ro);
         ngw = FUSED ? gscale / expf(w + 1e-6f) : w;
-        nam = ap[ro];
+        nam = buf_load_u8(ap, cl >> 2, ro);
     };
     // emit output row t held in slot TS (values X/Y/GW/AM of row t live in the same slot)
     auto emit = [&](int t, int /*unused*/, const float (&acc)[S][3][3], const float (&X)[S][3], const float (&Y)[3], float gw,
@@ -439,7 +487,7 @@ __global__ __launch_bounds__(64 * kWaves) void photo_bwd_kernel(PhotoBwdParams P
     for (int r = g.y0; r <= rlast; r += 3) {
         {   // r in slot 2; window j=r-1 in slot 1; output t=r-2 in slot 0
             bwd_place<S, 2>(st, nx, ny, ngw, nam);
-            if (r + 1 <= rlast) load_row(r + 1);
+            load_row(r + 1);
             const int j = r - 1;
             bwd_window<S, 0, 1, 2>(st, col_exists && j >= 0 && j < H, P.s_offset, wL, wR, wU(r), wD(r - 2));
             if (r - 2 >= g.y0) { row_of(0, X, Y); emit(r - 2, 0, st.ACC[0], X, Y, st.GW[0], st.AM[0]); }
@@ -447,7 +495,7 @@ __global__ __launch_bounds__(64 * kWaves) void photo_bwd_kernel(PhotoBwdParams P
         if (r + 1 > rlast) break;
         {   // r+1 in slot 0; window in slot 2; output in slot 1
             bwd_place<S, 0>(st, nx, ny, ngw, nam);
-            if (r + 2 <= rlast) load_row(r + 2);
+            load_row(r + 2);
             const int j = r;
             bwd_window<S, 1, 2, 0>(st, col_exists && j >= 0 && j < H, P.s_offset, wL, wR, wU(r + 1), wD(r - 1));
             if (r - 1 >= g.y0) { row_of(1, X, Y); emit(r - 1, 0, st.ACC[1], X, Y, st.GW[1], st.AM[1]); }
@@ -455,7 +503,7 @@ __global__ __launch_bounds__(64 * kWaves) void photo_bwd_kernel(PhotoBwdParams P
         if (r + 2 > rlast) break;
         {   // r+2 in slot 1; window in slot 0; output in slot 2
             bwd_place<S, 1>(st, nx, ny, ngw, nam);
-            if (r + 3 <= rlast) load_row(r + 3);
+            load_row(r + 3);
             const int j = r + 1;
             bwd_window<S, 2, 0, 1>(st, col_exists && j >= 0 && j < H, P.s_offset, wL, wR, wU(r + 2), wD(r));
             { row_of(2, X, Y); emit(r, 0, st.ACC[2], X, Y, st.GW[2], st.AM[2]); }
@@ -472,10 +520,11 @@ __global__ __launch_bounds__(64 * kWaves) void ssim_bwd_kernel(const float* __re
                                                                int nbx, int nby, int RB, float* __restrict__ g_preds) {
     const BandGeom g = band_geom<2>(nplanes, H, W, nbx, nby, RB);
     if (!g.active) return;
+    const unsigned cl = (unsigned)g.cl * 4u;  // lane's column byte offset: the only per-lane part of a load address
     const size_t HW = (size_t)H * W;
-    const float* xp = preds + (size_t)g.b * HW + g.cl;
-    const float* yp = targets + (size_t)g.b * HW + g.cl;
-    const float* wp = g_out + (size_t)g.b * HW + g.cl;
+    const float* xp = preds + (size_t)g.b * HW;
+    const float* yp = targets + (size_t)g.b * HW;
+    const float* wp = g_out + (size_t)g.b * HW;
     float* gp = g_preds + (size_t)g.b * HW + g.col;
     const bool col_exists = g.col >= 0 && g.col < W;
     const bool lane_out = g.lane >= 2 && g.lane <= 61 && g.col < W;
@@ -483,9 +532,9 @@ __global__ __launch_bounds__(64 * kWaves) void ssim_bwd_kernel(const float* __re
     float X[3], Y[3], GW[3], ACC[3][3];
     auto place = [&](int slot, int r) {
         const size_t ro = (size_t)reflect_idx(r, H) * W;
-        X[slot] = xp[ro];
-        Y[slot] = yp[ro];
-        GW[slot] = wp[ro];
+        X[slot] = (xp + ro)[cl >> 2];
+        Y[slot] = (yp + ro)[cl >> 2];
+        GW[slot] = (wp + ro)[cl >> 2];
     };
     auto window = [&](int T, int M, int Bt, bool exists, float wUn, float wDp) {
         float ax, axx, axy, ay, ayy;
@@ -536,22 +585,49 @@ __global__ __launch_bounds__(64 * kWaves) void ssim_bwd_kernel(const float* __re
 // ---------------------------------------------------------------------------------------------------
 struct Geom { int nbx, nby, RB, nblocks, nwaves; };
 
+inline int simd_count() {  // SIMDs of the current device (4 per CU); cached, devices of one node are alike
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        n = 4 * cus;
+    }
+    return n;
+}
+
+// Rows per wave.  The kernels are VALU-bound, so a launch takes about (waves on the busiest SIMD) x (rows a wave
+// walks, halo rows included); a SIMD needs two resident waves to issue back to back.  Pick the row chunk that
+// minimises that product: small batches get chunks sized so that the waves divide evenly over the SIMDs, large
+// ones get long chunks (less halo re-computation).  Pure function of (B,H,W,halo): the workspace size, the
+// partial-sum layout and both launches of a step derive the same geometry from it.
 inline Geom make_geom(int B, int H, int W, int halo) {
     Geom g;
     const int useful = 64 - 2 * halo;
     g.nbx = (W + useful - 1) / useful;
-    // rows per wave: enough waves to fill 256 CUs x 4 SIMDs a few times over, but keep the halo re-read small
-    int RB = 32;
-    while (RB > 8 && (long long)B * g.nbx * ((H + RB - 1) / RB) < 4096) RB >>= 1;
-    g.RB = RB;
-    g.nby = (H + RB - 1) / RB;
+    const double simds = (double)simd_count();
+    const long long bands = (long long)B * g.nbx;
+    double best = 1e300;
+    int best_nby = 1;
+    for (int nby = 1; nby <= (H + 3) / 4; ++nby) {
+        const int RB = (H + nby - 1) / nby;
+        if (nby > 1 && (nby - 1) * RB >= H) continue;  // same chunking as a smaller nby
+        const double w = (double)(bands * nby) / simds;
+        const double rounds = w <= 1.0 ? 1.85 : (w <= 4.0 ? ceil(w - 1e-9) : w + 0.5);
+        const double cost = rounds * (RB + 2 * halo);
+        if (cost < best - 1e-9) { best = cost; best_nby = nby; }
+    }
+    g.nby = best_nby;
+    g.RB = (H + g.nby - 1) / g.nby;
     g.nwaves = B * g.nbx * g.nby;
     g.nblocks = (g.nwaves + kWaves - 1) / kWaves;
     return g;
 }
 
 inline bool bad_dims(int B, int S, int H, int W) {
-    return B <= 0 || S <= 0 || H < 2 || W < 2 || (long long)H * W > (1ll << 30) || (long long)B * H * W > (1ll << 31);
+    return B <= 0 || S <= 0 || H < 2 || W < 2 || (long long)H * W > (1ll << 30) || (long long)B * H * W > (1ll << 31) ||
+           (long long)DS_MAX_SOURCES * 3 * H * W * 4 >= (1ll << 32);  // 32-bit buffer offsets inside one launch's planes of an image
 }
 
 template <bool IDT>

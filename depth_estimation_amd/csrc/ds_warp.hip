@@ -69,10 +69,11 @@ __device__ __forceinline__ void finish_grid_grad(const Samp& s, int Hs, int Ws, 
 
 __device__ __forceinline__ void scatter_src_grad(float* __restrict__ gp, const Corners& co, const Samp& s, float g) {
     if (g == 0.0f) return;
-    atomicAdd(gp + co.o_nw, g * s.w_nw);
-    if (co.xin) atomicAdd(gp + co.o_ne, g * s.w_ne);
-    if (co.yin) atomicAdd(gp + co.o_sw, g * s.w_sw);
-    if (co.xin && co.yin) atomicAdd(gp + co.o_se, g * s.w_se);
+    const int sh = co.shift ? 1 : 0;
+    atomicAdd(gp + co.o_top + sh, g * s.w_nw);
+    if (co.xin) atomicAdd(gp + co.o_top + 1, g * s.w_ne);
+    if (co.yin) atomicAdd(gp + co.o_bot + sh, g * s.w_sw);
+    if (co.xin && co.yin) atomicAdd(gp + co.o_bot + 1, g * s.w_se);
 }
 
 template <int C>

@@ -31,7 +31,7 @@ extern "C" {
 #define DS_ERR_WORKSPACE   (-3)
 
 #define DS_MAX_SOURCES 4        /* S per launch of the loss kernels (the reference uses S = SEQ_LEN-1 = 3) */
-#define DS_AUX_ARGMIN_MASK 0x1f /* aux byte: bits 0-4 argmin source, bits 5-7 clamp-pass flags of channels 0-2 */
+#define DS_AUX_ARGMIN_MASK 0x1f /* aux byte: bits 0-4 argmin source, bits 5-7 reserved (0) */
 
 int ds_version(void);
 const char* ds_error_string(int code);

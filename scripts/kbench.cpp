@@ -1,0 +1,81 @@
+// kbench: times the four C-ABI calls of one fused reprojection-loss step for a given libdepthsynth build.
+//   scripts/kbench <lib.so> B S H W iters
+// Build: hipcc -O2 -o scripts/kbench scripts/kbench.cpp -ldl
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+#include <random>
+#include <string>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef int (*warp_fwd_t)(const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, int, float*, void*);
+typedef int (*warp_bwd_t)(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, int, float*, float*, float*, void*, size_t, void*);
+typedef size_t (*ws3_t)(int, int, int);
+typedef int (*loss_fwd_t)(const float*, const float*, const float*, int, int, int, int, float*, float*, uint8_t*, float*, void*, size_t, void*);
+typedef int (*loss_bwd_t)(const float*, const float*, const float*, const uint8_t*, const float*, int, int, int, int, float*, void*);
+
+static float* dev_rand(size_t n, float lo, float hi, unsigned seed) {
+    std::vector<float> h(n);
+    std::mt19937 g(seed);
+    std::uniform_real_distribution<float> d(lo, hi);
+    for (auto& v : h) v = d(g);
+    float* p; CK(hipMalloc(&p, n * 4)); CK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice));
+    return p;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 7) { fprintf(stderr, "usage: kbench lib B S H W iters\n"); return 2; }
+    void* h = dlopen(argv[1], RTLD_NOW);
+    if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
+    int B = atoi(argv[2]), S = atoi(argv[3]), H = atoi(argv[4]), W = atoi(argv[5]), iters = atoi(argv[6]);
+    auto warp_fwd = (warp_fwd_t)dlsym(h, "ds_warp_fwd");
+    auto warp_bwd = (warp_bwd_t)dlsym(h, "ds_warp_bwd");
+    auto loss_fwd = (loss_fwd_t)dlsym(h, "ds_fused_loss_fwd");
+    auto loss_bwd = (loss_bwd_t)dlsym(h, "ds_fused_loss_bwd");
+    auto ws_loss = (ws3_t)dlsym(h, "ds_fused_loss_workspace_bytes");
+    auto ws_warp = (ws3_t)dlsym(h, "ds_warp_bwd_workspace_bytes");
+    const int N = B * S; const size_t HW = (size_t)H * W;
+    float* src = dev_rand(N * 3 * HW, 0, 1, 1);
+    float* tgt = dev_rand(B * 3 * HW, 0, 1, 2);
+    float* depth = dev_rand(N * HW, 1, 80, 3);
+    // K = normalised KITTI intrinsics scaled by W,H; Kinv its inverse; pose = identity + small translation
+    float fx = 0.58f * W, fy = 1.92f * H, cx = 0.5f * W, cy = 0.5f * H;
+    float Kh[16] = {fx, 0, cx, 0, 0, fy, cy, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    float Kih[16] = {1 / fx, 0, -cx / fx, 0, 0, 1 / fy, -cy / fy, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::vector<float> ph(N * 12, 0.f);
+    for (int n = 0; n < N; ++n) { ph[n * 12 + 0] = ph[n * 12 + 5] = ph[n * 12 + 10] = 1.f; ph[n * 12 + 3] = 0.05f * (n % 3); ph[n * 12 + 11] = 0.1f; }
+    float *K, *Kinv, *pose; CK(hipMalloc(&K, 64)); CK(hipMalloc(&Kinv, 64)); CK(hipMalloc(&pose, N * 48));
+    CK(hipMemcpy(K, Kh, 64, hipMemcpyHostToDevice)); CK(hipMemcpy(Kinv, Kih, 64, hipMemcpyHostToDevice));
+    CK(hipMemcpy(pose, ph.data(), N * 48, hipMemcpyHostToDevice));
+    float *warped, *out, *idt, *sums, *g_sums, *g_warped, *g_depth, *g_pose; uint8_t* aux; void *w1, *w2;
+    CK(hipMalloc(&warped, N * 3 * HW * 4)); CK(hipMalloc(&out, B * HW * 4)); CK(hipMalloc(&idt, B * HW * 4));
+    CK(hipMalloc(&aux, B * HW)); CK(hipMalloc(&sums, B * 8)); CK(hipMalloc(&g_warped, N * 3 * HW * 4));
+    CK(hipMalloc(&g_depth, N * HW * 4)); CK(hipMalloc(&g_pose, N * 48));
+    std::vector<float> ones(B, 1.f); CK(hipMalloc(&g_sums, B * 4)); CK(hipMemcpy(g_sums, ones.data(), B * 4, hipMemcpyHostToDevice));
+    size_t n1 = ws_loss(B, H, W), n2 = ws_warp(N, H, W);
+    CK(hipMalloc(&w1, n1 ? n1 : 4)); CK(hipMalloc(&w2, n2 ? n2 : 4));
+    hipStream_t st = 0;
+    hipEvent_t e[5]; for (auto& x : e) CK(hipEventCreate(&x));
+    double t[4] = {0, 0, 0, 0};
+    for (int it = -3; it < iters; ++it) {
+        CK(hipEventRecord(e[0], st));
+        int rc = warp_fwd(K, Kinv, pose, depth, src, N, 3, H, W, H, W, warped, st); if (rc) { fprintf(stderr, "warp_fwd rc=%d\n", rc); return 1; }
+        CK(hipEventRecord(e[1], st));
+        rc = loss_fwd(warped, src, tgt, B, S, H, W, out, idt, aux, sums, w1, n1, st); if (rc) { fprintf(stderr, "loss_fwd rc=%d\n", rc); return 1; }
+        CK(hipEventRecord(e[2], st));
+        rc = loss_bwd(warped, tgt, idt, aux, g_sums, B, S, H, W, g_warped, st); if (rc) { fprintf(stderr, "loss_bwd rc=%d\n", rc); return 1; }
+        CK(hipEventRecord(e[3], st));
+        rc = warp_bwd(K, Kinv, pose, depth, src, g_warped, N, 3, H, W, H, W, g_depth, g_pose, nullptr, w2, n2, st); if (rc) { fprintf(stderr, "warp_bwd rc=%d\n", rc); return 1; }
+        CK(hipEventRecord(e[4], st));
+        CK(hipStreamSynchronize(st));
+        if (it >= 0) for (int k = 0; k < 4; ++k) { float ms; CK(hipEventElapsedTime(&ms, e[k], e[k + 1])); t[k] += ms; }
+    }
+    std::vector<float> hs(B * 2); CK(hipMemcpy(hs.data(), sums, B * 8, hipMemcpyDeviceToHost));
+    printf("%-40s B=%d S=%d %dx%d  warp_fwd %.4f  loss_fwd %.4f  loss_bwd %.4f  warp_bwd %.4f ms  (sum %.4f)  loss[0]=%.6f\n", argv[1], B, S, H, W,
+           t[0] / iters, t[1] / iters, t[2] / iters, t[3] / iters, (t[0] + t[1] + t[2] + t[3]) / iters, hs[0]);
+    return 0;
+}
