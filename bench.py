@@ -229,6 +229,13 @@ def main():
     kern_ms = {n: sum(a.elapsed_time(b) for a, b in ev[n]) / args.steps for n in names}
     dom = max(names, key=lambda n: kern_ms[n])
     achieved = sc0.alg_bytes[dom] / (kern_ms[dom] * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes of the same command (profiles/traffic.json; null if not collected)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            traffic = json.load(fh).get(args.workload, {}).get(dom)
+    except (OSError, ValueError):
+        pass
     step_bytes = sum(sum(sc.alg_bytes.values()) for sc in scales)
 
     if rank == 0:
@@ -241,7 +248,7 @@ def main():
                        "height": wl["H"], "width": wl["W"], "scales": wl["scales"], "image_grad": bool(args.image_grad),
                        "launch": "hipgraph" if args.graph else "eager", "parallelism": f"batch-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "alg_bytes_per_launch": sc0.alg_bytes[dom], "avg_ms": round(kern_ms[dom], 5)},
             "kernels_ms": {n: round(kern_ms[n], 5) for n in names},
             "step_alg_GBps": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
