@@ -14,12 +14,17 @@
 // rounded divide: bit-identical to torch's avg_pool2d.  VALU-heavy by necessity:
 // 5 window sums x 9 taps per (pixel, channel, image pair) cannot be shared between windows without
 // changing the rounding order.
+#ifndef DS_DYN_LDS
+#define DS_DYN_LDS 0
+#endif
 #ifndef DS_EXP
-#define DS_EXP 0
+#define DS_EXP 0   // experiments (scripts/build_exp.sh), forward kernel, bit mask: 1 = synthetic row values instead of
+                   // global loads, 2 = no cross-wave combine (no barrier), 4 = no LDS neighbour exchange, 8 = no SSIM formula
 #endif
 #include "ds_common.h"
 #include "depthsynth.h"
 #include <math.h>
+#include <stdlib.h>
 
 using namespace ds;
 
@@ -68,6 +73,231 @@ struct PhotoFwdParams {
     float* wave_partials;   // (nwaves, 2), IDT only
 };
 
+// Rolling 3x3 window sum of one plane, one lane = one column.  Row r arrives as (L, C, R) = the values at columns
+// x-1, x, x+1; the call returns the finished sum of the window centred on row r-1 and advances the two partial sums:
+//   T = (L+C)+R                      of the newest row            (first row of the window centred on r+1)
+//   M = ((T' +L)+C)+R                T' = T of the row before     (first two rows of the window centred on r)
+//   w = ((M' +L)+C)+R                M' = M of the row before     (all three rows of the window centred on r-1)
+// which is the sequential row-major order of torch's avg_pool2d (the leading 0+ is exact): 8 plain adds per plane and
+// pixel, no cross-lane operand.
+struct Roll { float T, M; };
+__device__ __forceinline__ float roll(Roll& s, float L, float C, float R) {
+    const float w = ((s.M + L) + C) + R;
+    s.M = ((s.T + L) + C) + R;
+    s.T = (L + C) + R;
+    return w;
+}
+
+constexpr int kLdsRow = 68;  // 64 columns + left/right halo column (+2 pad)
+
+// One workgroup = four waves on one band of 64 adjacent columns (all of them useful), walking down a row chunk
+// together: three "channel waves", one per colour channel, and one "E wave".
+//
+// A channel wave holds the NP = 1 + G planes of its channel (target, then the G pred groups).  For every row the
+// lane's own values (and, in lanes 0 / 63, the halo columns left / right of the band) go through a per-wave LDS row
+// from which each lane reads its left and right neighbours: the stencil's cross-lane traffic rides on the LDS pipe
+// and the VALU sees only plain adds (a DPP operand halves the issue rate of the add that carries it).  LDS
+// instructions of one wave execute in order and no other wave touches a wave's exchange rows: no barrier for that.
+// Splitting the channels over waves keeps a wave near 110 VGPRs, i.e. four workgroups per CU: one gfx950 wave issues
+// a VALU instruction every ~4.4 cycles at best and a SIMD can issue one every 2 (scripts/ubench4/5), so a VALU-bound
+// kernel wants >= 3 runnable waves per SIMD.  A workgroup of four waves puts one wave on each SIMD of the CU (three-
+// wave workgroups left the fourth SIMD idle: -25 %).
+//
+// The per-channel errors e_c meet in a double-buffered LDS slab of kK rows: a channel wave writes its e_c there and
+// joins one s_barrier per kK rows; the E wave forms ((e0+e1)+e2)/3, the min over sources, the identity min, the
+// ratio and the sums for the slab the channel waves finished before, while they fill the other one.  The E wave is
+// light (~80 of ~1070 VALU instructions per row); the role of wave w rotates with the workgroup index so that the
+// light waves spread evenly over the four SIMDs.
+constexpr int kFwdWaves = 4;
+
+template <int S, bool IDT>
+__global__ __launch_bounds__(64 * kFwdWaves, 4) void photo_fwd_kernel(PhotoFwdParams P) {
+    constexpr int G = IDT ? 2 * S : S;
+    constexpr int NP = 1 + G;
+    constexpr int kK = G <= 4 ? 4 : 2;  // rows per barrier (slab = 2 * kK * 3 * G * 256 B of LDS)
+    __shared__ float lds_x[3][NP][kLdsRow];
+    __shared__ float lds_e[2][kK][3][G][64];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int role = (wave + (int)(blockIdx.x >> 3)) & 3;  // 0..2 = channel, 3 = E wave
+    const int lane = threadIdx.x & 63;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = wg % P.nbx, t = wg / P.nbx, by = t % P.nby, b = t / P.nby;
+    const int H = P.H, W = P.W;
+    const int y0 = by * P.RB, yend = min(y0 + P.RB, H);
+    const int c0 = bx * 64, col = c0 + lane;
+    const size_t HW = (size_t)H * W;
+
+    if (role == 3) {
+        // ---------------------------------------------------------------------------------- E wave
+        const bool lane_out = col < W;
+        float sum_ratio = 0.f, sum_out = 0.f;
+        const int nrows = yend - y0;
+        for (int k0 = 0; k0 < nrows; k0 += kK) {
+            __syncthreads();  // the channel waves have filled slab (k0 / kK) & 1
+            const int buf = (k0 / kK) & 1;
+            const int kn = min(kK, nrows - k0);
+            for (int k = 0; k < kn; ++k) {
+                float E[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    E[g] = div3((lds_e[buf][k][0][g][lane] + lds_e[buf][k][1][g][lane]) + lds_e[buf][k][2][g][lane]);
+                const int y = y0 + k0 + k;
+                float best = E[0];
+                int bi = 0;
+#pragma unroll
+                for (int s = 1; s < S; ++s)
+                    if (E[s] < best) { best = E[s]; bi = s; }
+                const size_t o = (size_t)b * HW + (size_t)y * W + col;
+                if (lane_out) {
+                    const unsigned a = (unsigned)(bi + P.s_offset);
+                    bool keep = true;
+                    if (P.s_offset > 0) keep = best < P.out[o];  // later chunk: strictly smaller wins (first index on ties)
+                    if (keep) {
+                        P.out[o] = best;
+                        if (P.aux) P.aux[o] = (uint8_t)a;
+                    }
+                    if (IDT) {
+                        float bid = E[S];
+#pragma unroll
+                        for (int s = 1; s < S; ++s) bid = fminf(bid, E[S + s]);
+                        P.idt[o] = bid;
+                        sum_ratio += best / expf(bid + 1e-6f);  // train.py:88
+                        sum_out += best;                        // train.py:92
+                    }
+                }
+            }
+        }
+        if (IDT) {
+            sum_ratio = wave_sum(sum_ratio);
+            sum_out = wave_sum(sum_out);
+            if (lane == 0) {
+                P.wave_partials[2 * wg + 0] = sum_ratio;
+                P.wave_partials[2 * wg + 1] = sum_out;
+            }
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------ channel wave
+    const int c = role;
+    const unsigned uHW = (unsigned)HW;
+    // per-lane byte offsets inside a row: own column, and the band's halo column (left for the lower half of the
+    // wave, right for the upper half; only lanes 0 and 63 store theirs)
+    const unsigned cl = (unsigned)reflect_idx(col, W) * 4u;
+    const unsigned ch = (unsigned)reflect_idx(lane < 32 ? c0 - 1 : c0 + 64, W) * 4u;
+    const bool edge = lane == 0 || lane == 63;
+    const int pad_slot = lane == 0 ? 0 : 65;
+    const rsrc_t tp = make_rsrc(P.target + (size_t)b * P.tgt_stride_b);
+    const rsrc_t pp = make_rsrc(P.preds + (size_t)b * P.pred_stride_b);
+    const rsrc_t sp = make_rsrc(IDT ? P.src + (size_t)b * (S * 3 * HW) : P.preds);
+    float (*lds)[kLdsRow] = lds_x[c];
+
+    // global loads of row r of this wave's channel: plane 0 = target, 1..S = preds, S+1..2S = un-warped sources
+    auto issue = [&](int r, float (&v)[NP], float (&h)[NP]) {
+        const unsigned ro = (unsigned)(reflect_idx(r, H) * W);
+#if DS_EXP & 1
+        const float base = 0.3f + 0.001f * (float)(r & 7) + 0.002f * (float)lane;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { v[p] = base * (1.0f + 0.1f * p); h[p] = v[p]; }
+        (void)ro;
+        return;
+#endif
+        v[0] = buf_load_f32(tp, cl, c * uHW + ro);
+        h[0] = buf_load_f32(tp, ch, c * uHW + ro);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            v[1 + s] = buf_load_f32(pp, cl, (s * 3 + c) * uHW + ro);
+            h[1 + s] = buf_load_f32(pp, ch, (s * 3 + c) * uHW + ro);
+            if (IDT) {
+                v[1 + S + s] = buf_load_f32(sp, cl, (s * 3 + c) * uHW + ro);
+                h[1 + S + s] = buf_load_f32(sp, ch, (s * 3 + c) * uHW + ro);
+            }
+        }
+    };
+    // neighbour exchange of one row.  The wavefront-scope fences emit no instruction; they keep the compiler from
+    // moving this thread's LDS reads above the writes of its neighbour lanes (different addresses, same wave).
+    auto exchange = [&](const float (&v)[NP], const float (&h)[NP], float (&L)[NP], float (&R)[NP]) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) lds[p][lane + 1] = v[p];
+        if (edge) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) lds[p][pad_slot] = h[p];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            L[p] = lds[p][lane];
+            R[p] = lds[p][lane + 2];
+        }
+    };
+
+    Roll Sy{0.f, 0.f}, Syy{0.f, 0.f}, Sx[G], Sxx[G], Sxy[G];
+    float Yp = 0.f, Xp[G];  // centre values of the previous row (the L1 term of the window being finished)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        Sx[g] = Sxx[g] = Sxy[g] = Roll{0.f, 0.f};
+        Xp[g] = 0.f;
+    }
+
+    float pend[NP], pendh[NP], cL[NP], cC[NP], cR[NP];
+    issue(y0 - 1, pend, pendh);
+    exchange(pend, pendh, cL, cR);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) cC[p] = pend[p];
+    issue(y0, pend, pendh);
+
+    // rows y0-1 and y0 only feed the partial sums; from row y0+1 on, row r finishes the windows centred on r-1
+    for (int r = y0 - 1; r <= yend; ++r) {
+        float nL[NP], nC[NP], nR[NP];
+        exchange(pend, pendh, nL, nR);  // row r+1
+#pragma unroll
+        for (int p = 0; p < NP; ++p) nC[p] = pend[p];
+        issue(r + 2, pend, pendh);      // two rows ahead (clamped past the chunk, then unused)
+
+        const float yL = cL[0], yC = cC[0], yR = cR[0];
+        const float ay = roll(Sy, yL, yC, yR);
+        const float ayy = roll(Syy, yL * yL, yC * yC, yR * yR);
+        float ax[G], axx[G], axy[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float xL = cL[1 + g], xC = cC[1 + g], xR = cR[1 + g];
+            ax[g] = roll(Sx[g], xL, xC, xR);
+            axx[g] = roll(Sxx[g], xL * xL, xC * xC, xR * xR);
+            axy[g] = roll(Sxy[g], xL * yL, xC * yC, xR * yR);
+        }
+        if (r > y0) {
+            const int k = r - y0 - 1;  // index of the finished output row inside the chunk
+            TgtStats ts;
+            target_stats(ay, ayy, ts);
+            float (*slab)[G][64] = lds_e[(k / kK) & 1][k % kK];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                SsimOut so;
+                ssim_from_sums(ax[g], axx[g], axy[g], ts, so);
+                slab[c][g][lane] = 0.85f * clamp01(so.v) + 0.15f * fabsf(Yp - Xp[g]);
+            }
+            if (k % kK == kK - 1 || r == yend) __syncthreads();  // slab full: hand it to the E wave
+        }
+        Yp = yC;
+#pragma unroll
+        for (int g = 0; g < G; ++g) Xp[g] = cC[1 + g];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            cL[p] = nL[p];
+            cC[p] = nC[p];
+            cR[p] = nR[p];
+        }
+    }
+}
+
+// =====================================================================================================
+// forward, register-lean variant for many groups (S >= 3 with the identity groups): three raw rows per plane in
+// registers, neighbours through DPP wave shifts folded into the adds, 62 useful columns per wave.  Same arithmetic,
+// same results; ~25 % slower per pixel than the LDS-exchange kernel above, but 3 registers per plane instead of 7.
+// =====================================================================================================
 template <int S, bool IDT>
 struct FwdState {
     static constexpr int G = IDT ? 2 * S : S;
@@ -94,32 +324,16 @@ __device__ __forceinline__ void fwd_window(FwdState<S, IDT>& st, float (&E)[FwdS
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float ay, ayy;
-#if DS_EXP == 2 || DS_EXP == 3
-        ay = st.Y[c][T] + st.Y[c][M]; ayy = st.Y[c][Bt];
-#else
         win_target(st.Y[c][T], st.Y[c][M], st.Y[c][Bt], ay, ayy);
-#endif
         TgtStats ts;
-#if DS_EXP == 1 || DS_EXP == 3
-        ts.my = ay; ts.my2 = ayy; ts.sy_raw = ay;
-#else
         target_stats(ay, ayy, ts);
-#endif
         const float yc = st.Y[c][M];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float ax, axx, axy;
-#if DS_EXP == 2 || DS_EXP == 3
-            ax = st.X[g][c][T]; axx = st.X[g][c][M]; axy = st.X[g][c][Bt];
-#else
             win_pair(st.X[g][c][T], st.X[g][c][M], st.X[g][c][Bt], st.Y[c][T], st.Y[c][M], st.Y[c][Bt], ax, axx, axy);
-#endif
             SsimOut so;
-#if DS_EXP == 1 || DS_EXP == 3
-            so.v = (ax + axx) + (axy + ts.my);
-#else
             ssim_from_sums(ax, axx, axy, ts, so);
-#endif
             const float e = 0.85f * clamp01(so.v) + 0.15f * fabsf(yc - st.X[g][c][M]);
             E[g] = (c == 0) ? e : E[g] + e;
         }
@@ -129,7 +343,7 @@ __device__ __forceinline__ void fwd_window(FwdState<S, IDT>& st, float (&E)[FwdS
 }
 
 template <int S, bool IDT>
-__global__ __launch_bounds__(64 * kWaves) void photo_fwd_kernel(PhotoFwdParams P) {
+__global__ __launch_bounds__(64 * kWaves) void photo_fwd_dpp_kernel(PhotoFwdParams P) {
     constexpr int G = FwdState<S, IDT>::G;
     const BandGeom g = band_geom<1>(P.B, P.H, P.W, P.nbx, P.nby, P.RB);
     if (!g.active) return;
@@ -146,19 +360,6 @@ __global__ __launch_bounds__(64 * kWaves) void photo_fwd_kernel(PhotoFwdParams P
     float nx[G][3], ny[3];
     auto load_row = [&](int r) {
         const unsigned ro = (unsigned)(reflect_idx(r, H) * W);
-#if DS_EXP == 4
-        const float base = 0.3f + 0.001f * (float)(r & 7) + 0.002f * (float)g.lane;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            ny[c] = base + 0.1f * c;
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                nx[s][c] = base * (1.1f + 0.1f * s) + 0.05f * c;
-                if (IDT) nx[S + s][c] = base * (0.9f - 0.1f * s) + 0.07f * c;
-            }
-        }
-        (void)ro;
-#else
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             ny[c] = buf_load_f32(tp, cl, c * uHW + ro);
@@ -168,7 +369,6 @@ __global__ __launch_bounds__(64 * kWaves) void photo_fwd_kernel(PhotoFwdParams P
                 if (IDT) nx[S + s][c] = buf_load_f32(sp, cl, (s * 3 + c) * uHW + ro);
             }
         }
-#endif
     };
     float sum_ratio = 0.f, sum_out = 0.f;
     auto emit = [&](int y, const float (&E)[G]) {
@@ -602,9 +802,8 @@ inline int simd_count() {  // SIMDs of the current device (4 per CU); cached, de
 // minimises that product: small batches get chunks sized so that the waves divide evenly over the SIMDs, large
 // ones get long chunks (less halo re-computation).  Pure function of (B,H,W,halo): the workspace size, the
 // partial-sum layout and both launches of a step derive the same geometry from it.
-inline Geom make_geom(int B, int H, int W, int halo) {
+inline Geom make_geom(int B, int H, int W, int halo, int useful, double halo_row_cost) {
     Geom g;
-    const int useful = 64 - 2 * halo;
     g.nbx = (W + useful - 1) / useful;
     const double simds = (double)simd_count();
     const long long bands = (long long)B * g.nbx;
@@ -615,7 +814,7 @@ inline Geom make_geom(int B, int H, int W, int halo) {
         if (nby > 1 && (nby - 1) * RB >= H) continue;  // same chunking as a smaller nby
         const double w = (double)(bands * nby) / simds;
         const double rounds = w <= 1.0 ? 1.85 : (w <= 4.0 ? ceil(w - 1e-9) : w + 0.5);
-        const double cost = rounds * (RB + 2 * halo);
+        const double cost = rounds * (RB + 2 * halo * halo_row_cost);
         if (cost < best - 1e-9) { best = cost; best_nby = nby; }
     }
     g.nby = best_nby;
@@ -625,20 +824,67 @@ inline Geom make_geom(int B, int H, int W, int halo) {
     return g;
 }
 
+// Forward loss kernels.  The channel-split LDS-exchange kernel (one 4-wave workgroup per band of 64 columns and row
+// chunk) is used wherever a wave's partial sums leave it below 128 VGPRs (G = groups per launch <= 4), the DPP kernel
+// (one wave per band of 62 useful columns) otherwise.
+inline bool fwd_uses_lds(int S, bool idt) { return (idt ? 2 * S : S) <= 4; }
+
+// Row chunking of the channel-split kernel: one workgroup per (band, row chunk); a CU holds four of them (VGPR
+// limit), the chip 4 * CUs at a time.  A chunk costs its rows plus about one row of lead-in, so chunks should be long;
+// on the other hand the launch balances itself only through workgroups that start when others finish.  Measured
+// (gpurun_out/kb14.txt): 320x1024 B=64 0.561 / 0.529 / 0.510 / 0.506 ms with 1 / 2 / 4 / 8 chunks per band, 192x640
+// B=12 flat between 8 and 24 chunks.  Rule: about eight rounds of workgroups, but chunks of at least 12 rows.
+// Pure function of (B,H,W): workspace size and launch derive the same geometry.
+inline Geom make_fwd_lds_geom(int B, int H, int W) {
+    Geom g;
+    g.nbx = (W + 63) / 64;
+    const long long capacity = simd_count();  // workgroups resident at once: 4 per CU = one per SIMD
+    const long long bands = (long long)B * g.nbx;
+    static const int forced = getenv("DS_FWD_NBY") ? atoi(getenv("DS_FWD_NBY")) : 0;  // tuning experiments only
+    long long nby = (8 * capacity + bands - 1) / bands;
+    const int max_nby = H / 12 > 1 ? H / 12 : 1;
+    if (nby > max_nby) nby = max_nby;
+    if (forced > 0) nby = forced < H ? forced : H;
+    g.RB = (H + (int)nby - 1) / (int)nby;
+    g.nby = (H + g.RB - 1) / g.RB;
+    g.nblocks = B * g.nbx * g.nby;
+    g.nwaves = g.nblocks;  // one partial-sum slot per workgroup
+    return g;
+}
+inline Geom make_fwd_geom(int B, int H, int W, int S, bool idt) {
+    return fwd_uses_lds(S, idt) ? make_fwd_lds_geom(B, H, W) : make_geom(B, H, W, 1, 62, 1.0);
+}
+
 inline bool bad_dims(int B, int S, int H, int W) {
     return B <= 0 || S <= 0 || H < 2 || W < 2 || (long long)H * W > (1ll << 30) || (long long)B * H * W > (1ll << 31) ||
            (long long)DS_MAX_SOURCES * 3 * H * W * 4 >= (1ll << 32);  // 32-bit buffer offsets inside one launch's planes of an image
 }
 
+// P carries everything but the geometry, which depends on the kernel variant S selects
 template <bool IDT>
-int launch_photo_fwd(int S, const PhotoFwdParams& P, int nblocks, hipStream_t st) {
-    dim3 g(nblocks), b(64 * kWaves);
-    switch (S) {
-        case 1: hipLaunchKernelGGL((photo_fwd_kernel<1, IDT>), g, b, 0, st, P); break;
-        case 2: hipLaunchKernelGGL((photo_fwd_kernel<2, IDT>), g, b, 0, st, P); break;
-        case 3: hipLaunchKernelGGL((photo_fwd_kernel<3, IDT>), g, b, 0, st, P); break;
-        case 4: hipLaunchKernelGGL((photo_fwd_kernel<4, IDT>), g, b, 0, st, P); break;
-        default: return DS_ERR_UNSUPPORTED;
+int launch_photo_fwd(int S, PhotoFwdParams P, Geom* geom_out, hipStream_t st) {
+    if (S < 1 || S > DS_MAX_SOURCES) return DS_ERR_UNSUPPORTED;
+    const Geom gm = make_fwd_geom(P.B, P.H, P.W, S, IDT);
+    P.nbx = gm.nbx; P.nby = gm.nby; P.RB = gm.RB;
+    if (geom_out) *geom_out = gm;
+    dim3 g(gm.nblocks), b(64 * kWaves);
+    if (fwd_uses_lds(S, IDT)) {
+        b = dim3(64 * kFwdWaves);
+        switch (IDT ? 2 * S : S) {  // instantiate only the variants fwd_uses_lds admits
+            case 1: hipLaunchKernelGGL((photo_fwd_kernel<1, false>), g, b, 0, st, P); break;
+            case 2: if (IDT) hipLaunchKernelGGL((photo_fwd_kernel<1, true>), g, b, 0, st, P);
+                    else hipLaunchKernelGGL((photo_fwd_kernel<2, false>), g, b, 0, st, P);
+                    break;
+            case 3: hipLaunchKernelGGL((photo_fwd_kernel<3, false>), g, b, 0, st, P); break;
+            case 4: if (IDT) hipLaunchKernelGGL((photo_fwd_kernel<2, true>), g, b, 0, st, P);
+                    else hipLaunchKernelGGL((photo_fwd_kernel<4, false>), g, b, 0, st, P);
+                    break;
+        }
+    } else {
+        switch (S) {  // IDT only
+            case 3: hipLaunchKernelGGL((photo_fwd_dpp_kernel<3, true>), g, b, 0, st, P); break;
+            case 4: hipLaunchKernelGGL((photo_fwd_dpp_kernel<4, true>), g, b, 0, st, P); break;
+        }
     }
     DS_CHECK_LAUNCH();
     return DS_OK;
@@ -648,10 +894,10 @@ template <bool FUSED>
 int launch_photo_bwd(int S, const PhotoBwdParams& P, int nblocks, hipStream_t st) {
     dim3 g(nblocks), b(64 * kWaves);
     switch (S) {
-        case 1: hipLaunchKernelGGL((photo_bwd_kernel<1, FUSED>), g, b, 0, st, P); break;
-        case 2: hipLaunchKernelGGL((photo_bwd_kernel<2, FUSED>), g, b, 0, st, P); break;
-        case 3: hipLaunchKernelGGL((photo_bwd_kernel<3, FUSED>), g, b, 0, st, P); break;
-        case 4: hipLaunchKernelGGL((photo_bwd_kernel<4, FUSED>), g, b, 0, st, P); break;
+        case 1: hipLaunchKernelGGL((photo_bwd_kernel<1, FUSED>), g, b, DS_DYN_LDS, st, P); break;
+        case 2: hipLaunchKernelGGL((photo_bwd_kernel<2, FUSED>), g, b, DS_DYN_LDS, st, P); break;
+        case 3: hipLaunchKernelGGL((photo_bwd_kernel<3, FUSED>), g, b, DS_DYN_LDS, st, P); break;
+        case 4: hipLaunchKernelGGL((photo_bwd_kernel<4, FUSED>), g, b, DS_DYN_LDS, st, P); break;
         default: return DS_ERR_UNSUPPORTED;
     }
     DS_CHECK_LAUNCH();
@@ -664,7 +910,7 @@ extern "C" {
 
 int ds_ssim_fwd(const float* preds, const float* targets, int nplanes, int H, int W, float* out, void* stream) {
     if (!preds || !targets || !out || bad_dims(nplanes, 1, H, W)) return DS_ERR_INVALID_ARG;
-    const Geom g = make_geom(nplanes, H, W, 1);
+    const Geom g = make_geom(nplanes, H, W, 1, 62, 1.0);
     hipLaunchKernelGGL(ssim_fwd_kernel, dim3(g.nblocks), dim3(64 * kWaves), 0, (hipStream_t)stream, preds, targets, nplanes,
                        H, W, g.nbx, g.nby, g.RB, out);
     DS_CHECK_LAUNCH();
@@ -674,7 +920,7 @@ int ds_ssim_fwd(const float* preds, const float* targets, int nplanes, int H, in
 int ds_ssim_bwd(const float* preds, const float* targets, const float* g_out, int nplanes, int H, int W, float* g_preds,
                 void* stream) {
     if (!preds || !targets || !g_out || !g_preds || bad_dims(nplanes, 1, H, W)) return DS_ERR_INVALID_ARG;
-    const Geom g = make_geom(nplanes, H, W, 2);
+    const Geom g = make_geom(nplanes, H, W, 2, 60, 1.0);
     hipLaunchKernelGGL(ssim_bwd_kernel, dim3(g.nblocks), dim3(64 * kWaves), 0, (hipStream_t)stream, preds, targets, g_out,
                        nplanes, H, W, g.nbx, g.nby, g.RB, g_preds);
     DS_CHECK_LAUNCH();
@@ -684,12 +930,11 @@ int ds_ssim_bwd(const float* preds, const float* targets, const float* g_out, in
 int ds_reprojection_loss_fwd(const float* preds, const float* targets, long long tgt_stride_b, long long tgt_stride_s,
                              int B, int S, int H, int W, float* out, uint8_t* aux, void* stream) {
     if (!preds || !targets || !out || bad_dims(B, S, H, W) || S > 32) return DS_ERR_INVALID_ARG;
-    const Geom g = make_geom(B, H, W, 1);
     const long long HW = (long long)H * W;
     PhotoFwdParams P{};
     P.pred_stride_b = (long long)S * 3 * HW;
     P.tgt_stride_b = tgt_stride_b;
-    P.B = B; P.H = H; P.W = W; P.nbx = g.nbx; P.nby = g.nby; P.RB = g.RB;
+    P.B = B; P.H = H; P.W = W;
     P.out = out; P.aux = aux;
     // one launch per chunk of sources that share a target; per-source targets go one source at a time
     const int chunk = tgt_stride_s == 0 ? DS_MAX_SOURCES : 1;
@@ -698,7 +943,7 @@ int ds_reprojection_loss_fwd(const float* preds, const float* targets, long long
         P.preds = preds + (long long)s0 * 3 * HW;
         P.target = targets + (long long)s0 * tgt_stride_s;
         P.s_offset = s0;
-        int rc = launch_photo_fwd<false>(n, P, g.nblocks, (hipStream_t)stream);
+        int rc = launch_photo_fwd<false>(n, P, nullptr, (hipStream_t)stream);
         if (rc != DS_OK) return rc;
     }
     return DS_OK;
@@ -708,7 +953,7 @@ int ds_reprojection_loss_bwd(const float* preds, const float* targets, long long
                              const float* g_out, const uint8_t* aux, int B, int S, int H, int W, float* g_preds,
                              void* stream) {
     if (!preds || !targets || !g_out || !aux || !g_preds || bad_dims(B, S, H, W) || S > 32) return DS_ERR_INVALID_ARG;
-    const Geom g = make_geom(B, H, W, 2);
+    const Geom g = make_geom(B, H, W, 2, 60, 1.0);
     const long long HW = (long long)H * W;
     PhotoBwdParams P{};
     P.pred_stride_b = (long long)S * 3 * HW;
@@ -731,8 +976,10 @@ int ds_reprojection_loss_bwd(const float* preds, const float* targets, long long
 
 size_t ds_fused_loss_workspace_bytes(int B, int H, int W) {
     if (B <= 0 || H < 2 || W < 2) return 0;
-    const Geom g = make_geom(B, H, W, 1);
-    return (size_t)g.nblocks * kWaves * 2 * sizeof(float);
+    // enough for either forward kernel variant (the entry point has no S)
+    const Geom g1 = make_fwd_geom(B, H, W, 1, true), g2 = make_fwd_geom(B, H, W, DS_MAX_SOURCES, true);
+    const size_t n1 = (size_t)g1.nwaves, n2 = (size_t)g2.nblocks * kWaves;
+    return (n1 > n2 ? n1 : n2) * 2 * sizeof(float);
 }
 
 int ds_fused_loss_fwd(const float* warped, const float* src, const float* target, int B, int S, int H, int W,
@@ -742,15 +989,15 @@ int ds_fused_loss_fwd(const float* warped, const float* src, const float* target
         return DS_ERR_INVALID_ARG;
     if (S > DS_MAX_SOURCES) return DS_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < ds_fused_loss_workspace_bytes(B, H, W)) return DS_ERR_WORKSPACE;
-    const Geom g = make_geom(B, H, W, 1);
     const long long HW = (long long)H * W;
     PhotoFwdParams P{};
     P.preds = warped; P.src = src; P.target = target;
     P.pred_stride_b = (long long)S * 3 * HW;
     P.tgt_stride_b = 3 * HW;
-    P.B = B; P.H = H; P.W = W; P.nbx = g.nbx; P.nby = g.nby; P.RB = g.RB;
+    P.B = B; P.H = H; P.W = W;
     P.out = out_loss; P.idt = idt_loss; P.aux = aux; P.wave_partials = (float*)workspace;
-    int rc = launch_photo_fwd<true>(S, P, g.nblocks, (hipStream_t)stream);
+    Geom g;
+    int rc = launch_photo_fwd<true>(S, P, &g, (hipStream_t)stream);
     if (rc != DS_OK) return rc;
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const float*)workspace,
                        g.nbx * g.nby, 1.0 / (double)HW, sums);
@@ -762,7 +1009,7 @@ int ds_fused_loss_bwd(const float* warped, const float* target, const float* idt
                       const float* g_sums, int B, int S, int H, int W, float* g_warped, void* stream) {
     if (!warped || !target || !idt_loss || !aux || !g_sums || !g_warped || bad_dims(B, S, H, W)) return DS_ERR_INVALID_ARG;
     if (S > DS_MAX_SOURCES) return DS_ERR_UNSUPPORTED;
-    const Geom g = make_geom(B, H, W, 2);
+    const Geom g = make_geom(B, H, W, 2, 60, 1.0);
     const long long HW = (long long)H * W;
     PhotoBwdParams P{};
     P.preds = warped; P.target = target; P.idt = idt_loss; P.g_sums = g_sums; P.aux = aux;

@@ -108,6 +108,10 @@ __global__ __launch_bounds__(kThreads) void grid_sample_bwd_kernel(const float* 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// pixels per thread.  Measured on MI355X (gpurun_out/kb8.txt): 4 pixels per thread -- 4 depth loads, then 4 x (2 x C)
+// corner-pair gathers in flight at once -- is no faster at 192x640 (27.0 vs 27.1 us) and 14 % slower at 320x1024, so 1.
+constexpr int kFwdPix = 1;
+
 template <int C>
 __global__ __launch_bounds__(kThreads) void warp_fwd_kernel(const float* __restrict__ K, const float* __restrict__ Kinv,
                                                             const float* __restrict__ pose,
@@ -115,25 +119,57 @@ __global__ __launch_bounds__(kThreads) void warp_fwd_kernel(const float* __restr
                                                             const float* __restrict__ src, int Cdyn, int Hs, int Ws,
                                                             int H, int W, float* __restrict__ warped) {
     const int n = blockIdx.y;
-    const int p = blockIdx.x * kThreads + threadIdx.x;
-    if (p >= H * W) return;
+    const int HW = H * W;
     const int Cc = C > 0 ? C : Cdyn;
     Cam cam;
     load_cam(cam, K, Kinv, pose + 12 * n);
-    const int y = p / W, x = p - y * W;
-    Proj pr;
-    project_pixel(cam, (float)x, (float)y, depth[(size_t)n * H * W + p], pr);
-    Samp s;
-    sample_setup(pr.u, pr.v, Hs, Ws, s);
-    Corners co;
-    corner_offsets(s, Hs, Ws, co);
     const float* sp = src + (size_t)n * Cc * Hs * Ws;
-    float* op = warped + (size_t)n * Cc * H * W + p;
+    const float* dp = depth + (size_t)n * HW;
+    // every thread handles kFwdPix pixels one block-width apart (each access stays a coalesced row segment); the
+    // loads of all of them are issued before any is consumed -- the kernel is bound by memory latency and gather
+    // address processing, not by arithmetic.  Out-of-range pixels are clamped for the loads and not stored.
+    int p[kFwdPix];
+    float d[kFwdPix];
 #pragma unroll
-    for (int c = 0; c < Cc; ++c) {
-        float nw, ne, sw, se;
-        gather4(sp + (size_t)c * Hs * Ws, co, nw, ne, sw, se);
-        op[(size_t)c * H * W] = bilinear(nw, ne, sw, se, s);
+    for (int k = 0; k < kFwdPix; ++k) {
+        p[k] = (blockIdx.x * kFwdPix + k) * kThreads + threadIdx.x;
+        d[k] = dp[min(p[k], HW - 1)];
+    }
+    Samp s[kFwdPix];
+    Corners co[kFwdPix];
+#pragma unroll
+    for (int k = 0; k < kFwdPix; ++k) {
+        const int pc = min(p[k], HW - 1);
+        const int y = pc / W, x = pc - y * W;
+        Proj pr;
+        project_pixel(cam, (float)x, (float)y, d[k], pr);
+        sample_setup(pr.u, pr.v, Hs, Ws, s[k]);
+        corner_offsets(s[k], Hs, Ws, co[k]);
+    }
+    if (C > 0) {
+        float nw[kFwdPix][C > 0 ? C : 1], ne[kFwdPix][C > 0 ? C : 1], sw[kFwdPix][C > 0 ? C : 1], se[kFwdPix][C > 0 ? C : 1];
+#pragma unroll
+        for (int k = 0; k < kFwdPix; ++k)
+#pragma unroll
+            for (int c = 0; c < C; ++c) gather4(sp + (size_t)c * Hs * Ws, co[k], nw[k][c], ne[k][c], sw[k][c], se[k][c]);
+#pragma unroll
+        for (int k = 0; k < kFwdPix; ++k)
+            if (p[k] < HW) {
+                float* op = warped + (size_t)n * C * HW + p[k];
+#pragma unroll
+                for (int c = 0; c < C; ++c) op[(size_t)c * HW] = bilinear(nw[k][c], ne[k][c], sw[k][c], se[k][c], s[k]);
+            }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kFwdPix; ++k)
+            if (p[k] < HW) {
+                float* op = warped + (size_t)n * Cc * HW + p[k];
+                for (int c = 0; c < Cc; ++c) {
+                    float nw, ne, sw, se;
+                    gather4(sp + (size_t)c * Hs * Ws, co[k], nw, ne, sw, se);
+                    op[(size_t)c * HW] = bilinear(nw, ne, sw, se, s[k]);
+                }
+            }
     }
 }
 
@@ -413,7 +449,7 @@ int ds_grid_sample_bwd(const float* src, const float* grid_norm, const float* g_
 int ds_warp_fwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src, int N,
                 int C, int Hs, int Ws, int H, int W, float* warped, void* stream) {
     if (!K || !Kinv || !pose || !depth || !src || !warped || bad_dims(N, C, Hs, Ws, H, W)) return DS_ERR_INVALID_ARG;
-    dim3 g(pix_blocks(H * W), N), b(kThreads);
+    dim3 g((H * W + kThreads * kFwdPix - 1) / (kThreads * kFwdPix), N), b(kThreads);
     if (C == 3)
         hipLaunchKernelGGL(warp_fwd_kernel<3>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, C, Hs, Ws, H, W,
                            warped);

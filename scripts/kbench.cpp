@@ -9,6 +9,7 @@
 #include <vector>
 #include <random>
 #include <string>
+#include <chrono>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -73,6 +74,43 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e[4], st));
         CK(hipStreamSynchronize(st));
         if (it >= 0) for (int k = 0; k < 4; ++k) { float ms; CK(hipEventElapsedTime(&ms, e[k], e[k + 1])); t[k] += ms; }
+    }
+    // ---- experiment: the batch split into `parts` sub-batches, each on its own stream (VALU-bound loss kernels of one
+    // part can overlap the gather-bound warp kernels of another); wall time of the whole step via host clock
+    if (argc > 7) {
+        const int parts = atoi(argv[7]);
+        std::vector<hipStream_t> ss(parts);
+        for (auto& x : ss) CK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+        const int Bp = B / parts, Np = Bp * S;
+        size_t n1p = ws_loss(Bp, H, W), n2p = ws_warp(Np, H, W);
+        std::vector<void*> w1p(parts), w2p(parts);
+        for (int p = 0; p < parts; ++p) { CK(hipMalloc(&w1p[p], n1p ? n1p : 4)); CK(hipMalloc(&w2p[p], n2p ? n2p : 4)); }
+        auto step = [&]() {
+            for (int p = 0; p < parts; ++p) {
+                const size_t o = (size_t)p * Np, ob = (size_t)p * Bp;
+                warp_fwd(K, Kinv, pose + o * 12, depth + o * HW, src + o * 3 * HW, Np, 3, H, W, H, W, warped + o * 3 * HW, ss[p]);
+            }
+            for (int p = 0; p < parts; ++p) {
+                const size_t o = (size_t)p * Np, ob = (size_t)p * Bp;
+                loss_fwd(warped + o * 3 * HW, src + o * 3 * HW, tgt + ob * 3 * HW, Bp, S, H, W, out + ob * HW, idt + ob * HW, aux + ob * HW, sums + ob * 2, w1p[p], n1p, ss[p]);
+            }
+            for (int p = 0; p < parts; ++p) {
+                const size_t o = (size_t)p * Np, ob = (size_t)p * Bp;
+                loss_bwd(warped + o * 3 * HW, tgt + ob * 3 * HW, idt + ob * HW, aux + ob * HW, g_sums + ob, Bp, S, H, W, g_warped + o * 3 * HW, ss[p]);
+            }
+            for (int p = 0; p < parts; ++p) {
+                const size_t o = (size_t)p * Np;
+                warp_bwd(K, Kinv, pose + o * 12, depth + o * HW, src + o * 3 * HW, g_warped + o * 3 * HW, Np, 3, H, W, H, W, g_depth + o * HW, g_pose + o * 12, nullptr, w2p[p], n2p, ss[p]);
+            }
+        };
+        for (int i = 0; i < 5; ++i) step();
+        CK(hipDeviceSynchronize());
+        hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < iters; ++i) step();
+        CK(hipDeviceSynchronize());
+        double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters;
+        printf("   split into %d parts on %d streams: %.4f ms per step\n", parts, parts, ms);
     }
     std::vector<float> hs(B * 2); CK(hipMemcpy(hs.data(), sums, B * 8, hipMemcpyDeviceToHost));
     printf("%-40s B=%d S=%d %dx%d  warp_fwd %.4f  loss_fwd %.4f  loss_bwd %.4f  warp_bwd %.4f ms  (sum %.4f)  loss[0]=%.6f\n", argv[1], B, S, H, W,

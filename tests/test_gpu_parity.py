@@ -290,9 +290,11 @@ def test_rejects_cpu_tensors_and_bad_shapes(de):
                                       torch.zeros(2, 3, 8, 8, device=DEV, dtype=torch.float64))
 
 
-@pytest.mark.parametrize("B,S,H,W", [(12, 2, 192, 640), (2, 4, 50, 131)])
+@pytest.mark.parametrize("B,S,H,W", [(12, 2, 192, 640), (2, 4, 50, 131), (3, 2, 37, 131), (2, 1, 9, 70), (1, 2, 5, 3),
+                                     (2, 3, 26, 64)])
 def test_full_size_against_oracle_and_properties(de, oracle, B, S, H, W):
-    """BASELINE config 2/3 size (and a ragged S=4 case): every sample against the oracle, plus
+    """BASELINE config 2/3 size (and ragged cases: S=4 and S=3 take the DPP forward kernel, S<=2 the channel-split one;
+    widths below, at and off multiples of the 64-column band): every sample against the oracle, plus
     size-independent properties: tie-breaking, linearity of the backward, batch independence."""
     g = torch.Generator().manual_seed(123)
     src = torch.rand(B, S, 3, H, W, generator=g)
@@ -301,12 +303,15 @@ def test_full_size_against_oracle_and_properties(de, oracle, B, S, H, W):
     vec = 0.01 * torch.randn(B * S, 6, generator=g)
     K, Kinv = de.fused.intrinsics(W, H)
     pose_np = oracle.pose_from_vec(vec.numpy()).reshape(B, S, 3, 4)
-    src[1, 1] = src[1, 0]; depth[1, 1] = depth[1, 0]; pose_np[1, 1] = pose_np[1, 0]   # a tie: first index must win
+    tie = B > 1 and S > 1
+    if tie:
+        src[1, 1] = src[1, 0]; depth[1, 1] = depth[1, 0]; pose_np[1, 1] = pose_np[1, 0]   # a tie: first index must win
     dd = depth.to(DEV).requires_grad_(True)
     pp = T(pose_np).requires_grad_(True)
     r = de.fused.fused_reprojection_loss(src.to(DEV), tgt.to(DEV), dd, pp, K.to(DEV), Kinv.to(DEV))
     (2.0 * r["loss"].sum()).backward()
-    assert not np.any((N(r["aux"])[1] & 0x1f) == 1)       # sources 0 and 1 of sample 1 are identical
+    if tie:
+        assert not np.any((N(r["aux"])[1] & 0x1f) == 1)   # sources 0 and 1 of sample 1 are identical
     Kn, Kin = K.numpy(), Kinv.numpy()
     for b in range(B):
         ow = np.stack([oracle.warp(Kn, Kin, pose_np[b, s], depth[b, s].numpy(), src[b, s].numpy(), H, W) for s in range(S)])
