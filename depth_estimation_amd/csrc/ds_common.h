@@ -134,6 +134,15 @@ __device__ __forceinline__ int buf_load_u8(rsrc_t r, unsigned lane_bytes, unsign
     return (int)__builtin_amdgcn_raw_buffer_load_b8(r, lane_bytes, uniform_bytes, 0);
 }
 
+typedef float float2_t __attribute__((ext_vector_type(2)));
+// two adjacent floats at a 4-byte aligned address (gfx950 buffer loads need no natural alignment)
+__device__ __forceinline__ float2_t buf_load_f32x2(rsrc_t r, unsigned lane_bytes, unsigned uniform_bytes) {
+    return __builtin_bit_cast(float2_t, __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, uniform_bytes, 0));
+}
+__device__ __forceinline__ void buf_store_f32(float v, rsrc_t r, unsigned lane_bytes, unsigned uniform_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, lane_bytes, uniform_bytes, 0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -168,6 +177,24 @@ __device__ __forceinline__ float div_noscale(float n, float d) {
     const float r0 = __builtin_amdgcn_rcpf(d);
     const float e0 = fmaf(-d, r0, 1.0f);
     const float r1 = fmaf(e0, r0, r0);
+    const float q0 = n * r1;
+    const float e1 = fmaf(-d, q0, n);
+    const float q1 = fmaf(e1, r1, q0);
+    const float e2 = fmaf(-d, q1, n);
+    return fmaf(e2, r1, q1);
+}
+
+// The same sequence split for several numerators over one denominator: r1 = rcp_refined(d) once (or, for a divisor
+// known on the host, the correctly rounded 1.0f/d), then 5 instructions per quotient.  Used by the warp kernels for
+// u = q0/z, v = q1/z (|z| >= 1e-6 by construction) and for the division by the source extent (Ws-1, Hs-1 >= 1):
+// operands far from the exponents where v_div_scale would rescale, results bit-identical to the IEEE divide
+// (tests/test_gpu_parity.py::test_warp_forward_bit_exact pins them against the oracle's true divide).
+__device__ __forceinline__ float rcp_refined(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = fmaf(-d, r0, 1.0f);
+    return fmaf(e0, r0, r0);
+}
+__device__ __forceinline__ float div_by(float n, float d, float r1) {
     const float q0 = n * r1;
     const float e1 = fmaf(-d, q0, n);
     const float q1 = fmaf(e1, r1, q0);

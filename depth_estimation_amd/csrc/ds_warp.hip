@@ -108,75 +108,170 @@ __global__ __launch_bounds__(kThreads) void grid_sample_bwd_kernel(const float* 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// pixels per thread.  Measured on MI355X (gpurun_out/kb8.txt): 4 pixels per thread -- 4 depth loads, then 4 x (2 x C)
-// corner-pair gathers in flight at once -- is no faster at 192x640 (27.0 vs 27.1 us) and 14 % slower at 320x1024, so 1.
-constexpr int kFwdPix = 1;
+// The two hot kernels (ds_warp_fwd / ds_warp_bwd) are VALU-heavy (~190 / ~300 instructions per pixel in their first
+// version, 60 % of their run time), so they are written for instruction count:
+//   * tiles instead of a flat pixel index (no integer division): a wave owns 64 adjacent columns of kRows rows, the
+//     four waves of a block sit below each other;
+//   * buffer loads / stores with the image base in an SGPR descriptor, a 32-bit lane offset and a uniform offset (no
+//     64-bit address arithmetic per access);
+//   * the divisions of the forward projection share one refined reciprocal per denominator (u = q0/z, v = q1/z) or
+//     take it from the host (division by Ws-1, Hs-1): 5 instructions per correctly rounded quotient instead of 12;
+//   * the border cases of the bilinear gather select WEIGHTS once per pixel, not texel values once per channel.
+struct WarpGeom {     // uniform launch geometry, filled by the host
+    int Hs, Ws, H, W, nbx;
+    float w1, h1;     // (float)(Ws-1), (float)(Hs-1)
+    float rw1, rh1;   // their correctly rounded reciprocals
+};
+
+struct Tap {
+    float ixu, iyu;                 // un-normalised, un-clipped coordinates (border rule of the backward)
+    float wx, ex, ny, sy;           // fractional weights
+    float wa_t, wb_t, wa_b, wb_b;   // weights of the loaded pairs: (a,b) of the top row, (a,b) of the bottom row
+    unsigned o_top, o_bot;          // byte offset of the left texel of each pair inside one source plane
+    bool shift;                     // x0 == Ws-1: the pair starts one texel to the left
+};
+
+// synthesis.synthesize's coordinate handling for one pixel (synthesis.py:49-54): normalise with the SOURCE dims,
+// un-normalise as grid_sample(align_corners=True), clip to the border, bilinear weights.  Same arithmetic as
+// ds_common.h sample_setup; the out-of-range corners get weight selection instead of value selection:
+//   x0 == Ws-1  => ix == Ws-1 exactly, wx == 0: the pair is loaded one texel to the left and its second texel takes
+//                  the nw/sw weight (the first gets 0, 0*texel + ... is exact for finite texels);
+//   y0 == Hs-1  => ny == 0: the bottom pair re-reads the top row with weights that are already 0.
+__device__ __forceinline__ void make_tap(float u, float v, const WarpGeom& G, Tap& t) {
+    const float gx = div_by(u, G.w1, G.rw1) * 2.0f - 1.0f;
+    const float gy = div_by(v, G.h1, G.rh1) * 2.0f - 1.0f;
+    float ix = (gx + 1.0f) * (G.w1 * 0.5f);
+    float iy = (gy + 1.0f) * (G.h1 * 0.5f);
+    t.ixu = ix;
+    t.iyu = iy;
+    ix = fminf(G.w1, fmaxf(ix, 0.0f));
+    iy = fminf(G.h1, fmaxf(iy, 0.0f));
+    const float xf = floorf(ix), yf = floorf(iy);
+    const int x0 = (int)xf, y0 = (int)yf;
+    t.wx = ix - xf;
+    t.ex = 1.0f - t.wx;
+    t.ny = iy - yf;
+    t.sy = 1.0f - t.ny;
+    const float w_nw = t.sy * t.ex, w_ne = t.sy * t.wx, w_sw = t.ny * t.ex, w_se = t.ny * t.wx;
+    t.shift = x0 + 1 >= G.Ws;
+    const int xc = t.shift ? x0 - 1 : x0;          // Ws >= 2 (checked on the host)
+    const int y1 = y0 + 1 < G.Hs ? y0 + 1 : y0;
+    t.o_top = (unsigned)(y0 * G.Ws + xc) * 4u;
+    t.o_bot = (unsigned)(y1 * G.Ws + xc) * 4u;
+    t.wa_t = t.shift ? 0.0f : w_nw;
+    t.wb_t = t.shift ? w_nw : w_ne;
+    t.wa_b = t.shift ? 0.0f : w_sw;
+    t.wb_b = t.shift ? w_sw : w_se;
+}
+
+// project_pixel with the two divisions sharing one refined reciprocal (kept in rz for the backward)
+__device__ __forceinline__ void project_pixel_lean(const Cam& cam, float fx, float fy, float d, Proj& o, float& rz) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float acc = fx * cam.Kinv[3 * j + 0];
+        acc = fmaf(fy, cam.Kinv[3 * j + 1], acc);
+        acc = fmaf(1.0f, cam.Kinv[3 * j + 2], acc);
+        o.c[j] = acc;
+        o.P[j] = acc * d;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float acc = o.P[0] * cam.M[4 * j + 0];
+        acc = fmaf(o.P[1], cam.M[4 * j + 1], acc);
+        acc = fmaf(o.P[2], cam.M[4 * j + 2], acc);
+        acc = fmaf(1.0f, cam.M[4 * j + 3], acc);
+        o.T[j] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float acc = o.T[0] * cam.K[3 * j + 0];
+        acc = fmaf(o.T[1], cam.K[3 * j + 1], acc);
+        acc = fmaf(o.T[2], cam.K[3 * j + 2], acc);
+        o.q[j] = acc;
+    }
+    o.z = (fabsf(o.q[2]) < 1e-6f) ? 1e-6f : o.q[2];
+    rz = rcp_refined(o.z);
+    o.u = div_by(o.q[0], o.z, rz);
+    o.v = div_by(o.q[1], o.z, rz);
+}
+
+constexpr int kFwdRows = 4;  // rows per wave: kFwdRows depth loads, then kFwdRows x C x 2 corner-pair gathers in flight
 
 template <int C>
 __global__ __launch_bounds__(kThreads) void warp_fwd_kernel(const float* __restrict__ K, const float* __restrict__ Kinv,
                                                             const float* __restrict__ pose,
                                                             const float* __restrict__ depth,
-                                                            const float* __restrict__ src, int Cdyn, int Hs, int Ws,
-                                                            int H, int W, float* __restrict__ warped) {
+                                                            const float* __restrict__ src, int Cdyn, WarpGeom G,
+                                                            float* __restrict__ warped) {
     const int n = blockIdx.y;
-    const int HW = H * W;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int bx = blockIdx.x % G.nbx, by = blockIdx.x / G.nbx;
+    const int yb = (by * (kThreads / 64) + wave) * kFwdRows;
+    if (yb >= G.H) return;
+    const int x = bx * 64 + lane, xc = min(x, G.W - 1);
     const int Cc = C > 0 ? C : Cdyn;
+    const unsigned HW = (unsigned)(G.H * G.W), HsWs = (unsigned)(G.Hs * G.Ws);
     Cam cam;
     load_cam(cam, K, Kinv, pose + 12 * n);
-    const float* sp = src + (size_t)n * Cc * Hs * Ws;
-    const float* dp = depth + (size_t)n * HW;
-    // every thread handles kFwdPix pixels one block-width apart (each access stays a coalesced row segment); the
-    // loads of all of them are issued before any is consumed -- the kernel is bound by memory latency and gather
-    // address processing, not by arithmetic.  Out-of-range pixels are clamped for the loads and not stored.
-    int p[kFwdPix];
-    float d[kFwdPix];
+    const rsrc_t dp = make_rsrc(depth + (size_t)n * HW);
+    const rsrc_t sp = make_rsrc(src + (size_t)n * Cc * HsWs);
+    const rsrc_t op = make_rsrc(warped + (size_t)n * Cc * HW);
+    const unsigned xb = (unsigned)xc * 4u;
+    float d[kFwdRows];
 #pragma unroll
-    for (int k = 0; k < kFwdPix; ++k) {
-        p[k] = (blockIdx.x * kFwdPix + k) * kThreads + threadIdx.x;
-        d[k] = dp[min(p[k], HW - 1)];
-    }
-    Samp s[kFwdPix];
-    Corners co[kFwdPix];
+    for (int i = 0; i < kFwdRows; ++i) d[i] = buf_load_f32(dp, xb, (unsigned)(min(yb + i, G.H - 1) * G.W));
+    Tap t[kFwdRows];
 #pragma unroll
-    for (int k = 0; k < kFwdPix; ++k) {
-        const int pc = min(p[k], HW - 1);
-        const int y = pc / W, x = pc - y * W;
+    for (int i = 0; i < kFwdRows; ++i) {
         Proj pr;
-        project_pixel(cam, (float)x, (float)y, d[k], pr);
-        sample_setup(pr.u, pr.v, Hs, Ws, s[k]);
-        corner_offsets(s[k], Hs, Ws, co[k]);
+        float rz;
+        project_pixel_lean(cam, (float)xc, (float)min(yb + i, G.H - 1), d[i], pr, rz);
+        make_tap(pr.u, pr.v, G, t[i]);
     }
     if (C > 0) {
-        float nw[kFwdPix][C > 0 ? C : 1], ne[kFwdPix][C > 0 ? C : 1], sw[kFwdPix][C > 0 ? C : 1], se[kFwdPix][C > 0 ? C : 1];
+        float2_t top[kFwdRows][C > 0 ? C : 1], bot[kFwdRows][C > 0 ? C : 1];
 #pragma unroll
-        for (int k = 0; k < kFwdPix; ++k)
+        for (int i = 0; i < kFwdRows; ++i)
 #pragma unroll
-            for (int c = 0; c < C; ++c) gather4(sp + (size_t)c * Hs * Ws, co[k], nw[k][c], ne[k][c], sw[k][c], se[k][c]);
-#pragma unroll
-        for (int k = 0; k < kFwdPix; ++k)
-            if (p[k] < HW) {
-                float* op = warped + (size_t)n * C * HW + p[k];
-#pragma unroll
-                for (int c = 0; c < C; ++c) op[(size_t)c * HW] = bilinear(nw[k][c], ne[k][c], sw[k][c], se[k][c], s[k]);
+            for (int c = 0; c < C; ++c) {
+                top[i][c] = buf_load_f32x2(sp, t[i].o_top, c * HsWs * 4u);
+                bot[i][c] = buf_load_f32x2(sp, t[i].o_bot, c * HsWs * 4u);
             }
-    } else {
 #pragma unroll
-        for (int k = 0; k < kFwdPix; ++k)
-            if (p[k] < HW) {
-                float* op = warped + (size_t)n * Cc * HW + p[k];
-                for (int c = 0; c < Cc; ++c) {
-                    float nw, ne, sw, se;
-                    gather4(sp + (size_t)c * Hs * Ws, co[k], nw, ne, sw, se);
-                    op[(size_t)c * HW] = bilinear(nw, ne, sw, se, s[k]);
+        for (int i = 0; i < kFwdRows; ++i) {
+            if (x < G.W && yb + i < G.H) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float acc = top[i][c].x * t[i].wa_t;
+                    acc = fmaf(top[i][c].y, t[i].wb_t, acc);
+                    acc = fmaf(bot[i][c].x, t[i].wa_b, acc);
+                    acc = fmaf(bot[i][c].y, t[i].wb_b, acc);
+                    buf_store_f32(acc, op, (unsigned)x * 4u, (c * HW + (unsigned)((yb + i) * G.W)) * 4u);
                 }
             }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kFwdRows; ++i) {
+            if (x < G.W && yb + i < G.H) {
+                for (int c = 0; c < Cc; ++c) {
+                    const float2_t tp = buf_load_f32x2(sp, t[i].o_top, c * HsWs * 4u);
+                    const float2_t bt = buf_load_f32x2(sp, t[i].o_bot, c * HsWs * 4u);
+                    float acc = tp.x * t[i].wa_t;
+                    acc = fmaf(tp.y, t[i].wb_t, acc);
+                    acc = fmaf(bt.x, t[i].wa_b, acc);
+                    acc = fmaf(bt.y, t[i].wb_b, acc);
+                    buf_store_f32(acc, op, (unsigned)x * 4u, (c * HW + (unsigned)((yb + i) * G.W)) * 4u);
+                }
+            }
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // warp backward: per pixel g_depth; per (n) 12-float pose gradient reduced wave -> block -> partial
 // buffer -> pose_finalize_kernel (fixed order: deterministic, no atomics); optional image scatter.
-constexpr int kBwdPix = 4;  // pixels per thread
+constexpr int kBwdPix = 4;  // pixels per thread (reproject_bwd_kernel)
 
 // autograd of project_pixel: (g_u, g_v) = d loss / d(u, v) -> g_depth, += pose gradient
 __device__ __forceinline__ void project_bwd_pixel(const Cam& cam, const Proj& pr, float gix, float giy, float& g_d,
@@ -216,51 +311,96 @@ __device__ __forceinline__ void block_reduce12(float (&gM)[12], float* __restric
     }
 }
 
+constexpr int kBwdRows = 8;  // rows per wave: the 12-float pose-gradient wave reduction is paid once per 8 pixels
+
 template <int C>
 __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restrict__ K, const float* __restrict__ Kinv,
                                                             const float* __restrict__ pose,
                                                             const float* __restrict__ depth,
                                                             const float* __restrict__ src,
-                                                            const float* __restrict__ g_warped, int Cdyn, int Hs, int Ws,
-                                                            int H, int W, float* __restrict__ g_depth,
-                                                            float* __restrict__ g_src, float* __restrict__ partials) {
+                                                            const float* __restrict__ g_warped, int Cdyn, WarpGeom G,
+                                                            float* __restrict__ g_depth, float* __restrict__ g_src,
+                                                            float* __restrict__ partials) {
     __shared__ float lds[kThreads / 64][12];
     const int n = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int bx = blockIdx.x % G.nbx, by = blockIdx.x / G.nbx;
+    const int yb = (by * (kThreads / 64) + wave) * kBwdRows;
+    const int x = bx * 64 + lane, xc = min(x, G.W - 1);
     const int Cc = C > 0 ? C : Cdyn;
-    const int HW = H * W;
+    const unsigned HW = (unsigned)(G.H * G.W), HsWs = (unsigned)(G.Hs * G.Ws);
     Cam cam;
     load_cam(cam, K, Kinv, pose + 12 * n);
+    const rsrc_t dp = make_rsrc(depth + (size_t)n * HW);
+    const rsrc_t sp = make_rsrc(src + (size_t)n * Cc * HsWs);
+    const rsrc_t gp = make_rsrc(g_warped + (size_t)n * Cc * HW);
+    const rsrc_t op = make_rsrc(g_depth + (size_t)n * HW);
+    const unsigned xb = (unsigned)xc * 4u;
     float gM[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) gM[i] = 0.f;
-    const float* sp = src + (size_t)n * Cc * Hs * Ws;
+    // un-normalise * normalise factors of the grid gradient (grid_sampler backward, then synthesis.py:50-51)
+    const float sx = (G.w1 * 0.5f) * (2.0f * G.rw1), sy = (G.h1 * 0.5f) * (2.0f * G.rh1);
+#pragma unroll 2
+    for (int i = 0; i < kBwdRows; ++i) {
+        const int y = yb + i;
+        if (y >= G.H) break;  // wave-uniform
+        const unsigned ro = (unsigned)(y * G.W);
+        const float d = buf_load_f32(dp, xb, ro);
+        float g[C > 0 ? C : 1];
+        if (C > 0) {
 #pragma unroll
-    for (int it = 0; it < kBwdPix; ++it) {
-        const int p = (blockIdx.x * kBwdPix + it) * kThreads + threadIdx.x;
-        if (p < HW) {
-            const int y = p / W, x = p - y * W;
-            Proj pr;
-            project_pixel(cam, (float)x, (float)y, depth[(size_t)n * HW + p], pr);
-            Samp s;
-            sample_setup(pr.u, pr.v, Hs, Ws, s);
-            Corners co;
-            corner_offsets(s, Hs, Ws, co);
-            const float* gp = g_warped + (size_t)n * Cc * HW + p;
-            float gix = 0.f, giy = 0.f;
-#pragma unroll
-            for (int c = 0; c < Cc; ++c) {
-                float nw, ne, sw, se;
-                gather4(sp + (size_t)c * Hs * Ws, co, nw, ne, sw, se);
-                float g = gp[(size_t)c * HW];
-                gix = fmaf(g, fmaf(ne - nw, s.sy, (se - sw) * s.ny), gix);
-                giy = fmaf(g, fmaf(sw - nw, s.ex, (se - ne) * s.wx), giy);
-                if (g_src) scatter_src_grad(g_src + ((size_t)n * Cc + c) * Hs * Ws, co, s, g);
-            }
-            float gd;
-            finish_grid_grad(s, Hs, Ws, gix, giy);
-            project_bwd_pixel(cam, pr, gix, giy, gd, gM);
-            g_depth[(size_t)n * HW + p] = gd;
+            for (int c = 0; c < C; ++c) g[c] = buf_load_f32(gp, xb, c * HW + ro);
         }
+        Proj pr;
+        float rz;
+        project_pixel_lean(cam, (float)xc, (float)y, d, pr, rz);
+        Tap t;
+        make_tap(pr.u, pr.v, G, t);
+        float gix = 0.f, giy = 0.f;
+        auto channel = [&](int c, float gc) {
+            const float2_t tp = buf_load_f32x2(sp, t.o_top, c * HsWs * 4u);
+            const float2_t bt = buf_load_f32x2(sp, t.o_bot, c * HsWs * 4u);
+            // corner texels; a corner outside the image only ever meets a zero weight or a zeroed gradient below
+            const float nw = t.shift ? tp.y : tp.x, ne = tp.y, sw = t.shift ? bt.y : bt.x, se = bt.y;
+            gix = fmaf(gc, fmaf(ne - nw, t.sy, (se - sw) * t.ny), gix);
+            giy = fmaf(gc, fmaf(sw - nw, t.ex, (se - ne) * t.wx), giy);
+        };
+        if (C > 0) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) channel(c, g[c]);
+        } else {
+            for (int c = 0; c < Cc; ++c) channel(c, buf_load_f32(gp, xb, c * HW + ro));
+        }
+        if (g_src && x < G.W) {  // optional image gradient: float atomics (off in the reference's own use)
+            Samp s;
+            sample_setup(pr.u, pr.v, G.Hs, G.Ws, s);
+            Corners co;
+            corner_offsets(s, G.Hs, G.Ws, co);
+            for (int c = 0; c < Cc; ++c)
+                scatter_src_grad(g_src + ((size_t)n * Cc + c) * HsWs, co, s, buf_load_f32(gp, xb, c * HW + ro));
+        }
+        // torch grid_sampler_2d backward: zero on or outside the border of the un-clipped coordinate
+        gix = (t.ixu > 0.0f && t.ixu < G.w1) ? gix * sx : 0.0f;
+        giy = (t.iyu > 0.0f && t.iyu < G.h1) ? giy * sy : 0.0f;
+        if (x >= G.W) gix = giy = 0.0f;  // lanes beyond the image contribute nothing to the pose gradient
+        // autograd of project_pixel (see project_bwd_pixel); 1/z from the forward's refined reciprocal
+        const float gq0 = gix * rz, gq1 = giy * rz;
+        const float gq2 = (fabsf(pr.q[2]) < 1e-6f) ? 0.0f : -(fmaf(pr.u, gix, pr.v * giy)) * rz;
+        float gT[3], gP[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gT[k] = fmaf(cam.K[6 + k], gq2, fmaf(cam.K[3 + k], gq1, cam.K[k] * gq0));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gP[k] = fmaf(cam.M[8 + k], gT[2], fmaf(cam.M[4 + k], gT[1], cam.M[k] * gT[0]));
+        const float gd = fmaf(pr.c[2], gP[2], fmaf(pr.c[1], gP[1], pr.c[0] * gP[0]));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            gM[4 * j + 0] = fmaf(gT[j], pr.P[0], gM[4 * j + 0]);
+            gM[4 * j + 1] = fmaf(gT[j], pr.P[1], gM[4 * j + 1]);
+            gM[4 * j + 2] = fmaf(gT[j], pr.P[2], gM[4 * j + 2]);
+            gM[4 * j + 3] += gT[j];
+        }
+        if (x < G.W) buf_store_f32(gd, op, (unsigned)x * 4u, ro * 4u);
     }
     block_reduce12(gM, partials + ((size_t)n * gridDim.x + blockIdx.x) * 12, lds);
 }
@@ -402,6 +542,19 @@ __global__ void pose_finalize_kernel(const float* __restrict__ partials, int nbl
 inline int pix_blocks(int HW) { return (HW + kThreads - 1) / kThreads; }
 inline int bwd_blocks(int HW) { return (HW + kThreads * kBwdPix - 1) / (kThreads * kBwdPix); }
 
+inline WarpGeom warp_geom(int Hs, int Ws, int H, int W) {
+    WarpGeom G;
+    G.Hs = Hs; G.Ws = Ws; G.H = H; G.W = W;
+    G.nbx = (W + 63) / 64;
+    G.w1 = (float)(Ws - 1); G.h1 = (float)(Hs - 1);
+    G.rw1 = 1.0f / G.w1; G.rh1 = 1.0f / G.h1;
+    return G;
+}
+inline int warp_tiles(int H, int W, int rows) {  // blocks per image: 64 columns x (4 waves x rows) rows each
+    const int per_block = (kThreads / 64) * rows;
+    return ((W + 63) / 64) * ((H + per_block - 1) / per_block);
+}
+
 inline bool bad_dims(int N, int C, int Hs, int Ws, int H, int W) {
     return N <= 0 || C <= 0 || Hs < 2 || Ws < 2 || H <= 0 || W <= 0 || N > 65535 ||
            (long long)H * W > (1ll << 30) || (long long)Hs * Ws > (1ll << 30);
@@ -449,20 +602,20 @@ int ds_grid_sample_bwd(const float* src, const float* grid_norm, const float* g_
 int ds_warp_fwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src, int N,
                 int C, int Hs, int Ws, int H, int W, float* warped, void* stream) {
     if (!K || !Kinv || !pose || !depth || !src || !warped || bad_dims(N, C, Hs, Ws, H, W)) return DS_ERR_INVALID_ARG;
-    dim3 g((H * W + kThreads * kFwdPix - 1) / (kThreads * kFwdPix), N), b(kThreads);
+    const WarpGeom G = warp_geom(Hs, Ws, H, W);
+    dim3 g(warp_tiles(H, W, kFwdRows), N), b(kThreads);
     if (C == 3)
-        hipLaunchKernelGGL(warp_fwd_kernel<3>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, C, Hs, Ws, H, W,
-                           warped);
+        hipLaunchKernelGGL(warp_fwd_kernel<3>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, C, G, warped);
     else
-        hipLaunchKernelGGL(warp_fwd_kernel<0>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, C, Hs, Ws, H, W,
-                           warped);
+        hipLaunchKernelGGL(warp_fwd_kernel<0>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, C, G, warped);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }
 
 size_t ds_warp_bwd_workspace_bytes(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)N * bwd_blocks(H * W) * 12 * sizeof(float);
+    const int a = bwd_blocks(H * W), b = warp_tiles(H, W, kBwdRows);  // ds_reproject_bwd / ds_warp_bwd partials
+    return (size_t)N * (a > b ? a : b) * 12 * sizeof(float);
 }
 
 int ds_warp_bwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
@@ -471,15 +624,16 @@ int ds_warp_bwd(const float* K, const float* Kinv, const float* pose, const floa
     if (!K || !Kinv || !pose || !depth || !src || !g_warped || !g_depth || !g_pose || bad_dims(N, C, Hs, Ws, H, W))
         return DS_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < ds_warp_bwd_workspace_bytes(N, H, W)) return DS_ERR_WORKSPACE;
-    const int nblk = bwd_blocks(H * W);
+    const WarpGeom G = warp_geom(Hs, Ws, H, W);
+    const int nblk = warp_tiles(H, W, kBwdRows);
     dim3 g(nblk, N), b(kThreads);
     float* partials = (float*)workspace;
     if (C == 3)
-        hipLaunchKernelGGL(warp_bwd_kernel<3>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, g_warped, C, Hs, Ws,
-                           H, W, g_depth, g_src, partials);
+        hipLaunchKernelGGL(warp_bwd_kernel<3>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, g_warped, C, G,
+                           g_depth, g_src, partials);
     else
-        hipLaunchKernelGGL(warp_bwd_kernel<0>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, g_warped, C, Hs, Ws,
-                           H, W, g_depth, g_src, partials);
+        hipLaunchKernelGGL(warp_bwd_kernel<0>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, g_warped, C, G,
+                           g_depth, g_src, partials);
     DS_CHECK_LAUNCH();
     hipLaunchKernelGGL(pose_finalize_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, partials, nblk, g_pose);
     DS_CHECK_LAUNCH();
