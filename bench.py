@@ -97,10 +97,15 @@ class Scale:
                 self.L.check(rc, name)
 
 
-def build_problem(de, wl, dev, rank, image_grad):
+def build_problem(de, wl, dev, rank, image_grad, parts=1):
+    """One Scale per (pyramid level, sub-batch).  With parts > 1 the B targets of a level are split into `parts`
+    independent sub-batches (own buffers, own workspaces), which the step launches on `parts` HIP streams."""
     scales = []
     for i in range(wl["scales"]):
-        scales.append(Scale(de, wl["B"], wl["S"], wl["H"] >> i, wl["W"] >> i, dev, 1000 * rank + i, image_grad))
+        for j in range(parts):
+            b = wl["B"] // parts + (1 if j < wl["B"] % parts else 0)
+            if b > 0:
+                scales.append(Scale(de, b, wl["S"], wl["H"] >> i, wl["W"] >> i, dev, 1000 * rank + 10 * i + j, image_grad))
     return scales
 
 
@@ -147,6 +152,9 @@ def main():
     ap.add_argument("--image-grad", action="store_true", help="also scatter the source-image gradient")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="sub-batches per step, each on its own HIP stream: the memory-bound warp kernels of one overlap "
+                         "the VALU-bound loss kernels of the other (1 = whole batch on one stream)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,12 +174,26 @@ def main():
 
     import depth_estimation_amd as de
     wl = WORKLOADS[args.workload]
-    scales = build_problem(de, wl, dev, rank, args.image_grad)
+    parts = 1 if args.graph else max(1, min(args.streams, wl["B"]))
+    scales = build_problem(de, wl, dev, rank, args.image_grad, parts)
     st = torch.cuda.current_stream().cuda_stream
+    side_streams = [torch.cuda.Stream() for _ in range(parts)] if parts > 1 else []
 
     def step():
+        if parts == 1:
+            for sc in scales:
+                sc.step(st)
+            return
+        # the four calls of every sub-batch, issued phase by phase so that each stream always has work queued
         for sc in scales:
-            sc.step(st)
+            if sc.g_src is not None:
+                sc.g_src.zero_()
+        for lvl in range(0, len(scales), parts):
+            for name in ("warp_fwd", "loss_fwd", "loss_bwd", "warp_bwd"):
+                for j, sc in enumerate(scales[lvl:lvl + parts]):
+                    rc = sc.calls[name](side_streams[j].cuda_stream)
+                    if rc != 0:
+                        sc.L.check(rc, name)
 
     graph = None
     if args.graph:
@@ -211,7 +233,12 @@ def main():
     value = world * warped_px_rank * args.steps / elapsed / 1e9
 
     # per-kernel durations: HIP events on the launch stream around each call, inside the same step sequence
+    # (whole batch of the finest level on the current stream, whatever --streams says: kernels do not overlap here)
     names = ("warp_fwd", "loss_fwd", "loss_bwd", "warp_bwd")
+    step_bytes = sum(sum(sc.alg_bytes.values()) for sc in scales)
+    if parts > 1:
+        del scales
+        scales = build_problem(de, wl, dev, rank, args.image_grad, 1)
     sc0 = scales[0]
     ev = {n: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
           for n in names}
@@ -236,7 +263,6 @@ def main():
             traffic = json.load(fh).get(args.workload, {}).get(dom)
     except (OSError, ValueError):
         pass
-    step_bytes = sum(sum(sc.alg_bytes.values()) for sc in scales)
 
     if rank == 0:
         line = {
@@ -246,7 +272,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "targets_per_gpu": wl["B"], "sources_per_target": wl["S"],
                        "height": wl["H"], "width": wl["W"], "scales": wl["scales"], "image_grad": bool(args.image_grad),
-                       "launch": "hipgraph" if args.graph else "eager", "parallelism": f"batch-sharded x{world}, no collective"},
+                       "launch": "hipgraph" if args.graph else ("eager" if parts == 1 else f"eager, {parts} sub-batches on {parts} streams"),
+                       "parallelism": f"batch-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "alg_bytes_per_launch": sc0.alg_bytes[dom], "avg_ms": round(kern_ms[dom], 5)},

@@ -195,7 +195,10 @@ __device__ __forceinline__ void project_pixel_lean(const Cam& cam, float fx, flo
     o.v = div_by(o.q[1], o.z, rz);
 }
 
-constexpr int kFwdRows = 4;  // rows per wave: kFwdRows depth loads, then kFwdRows x C x 2 corner-pair gathers in flight
+#ifndef DS_FWD_ROWS
+#define DS_FWD_ROWS 4
+#endif
+constexpr int kFwdRows = DS_FWD_ROWS;  // rows per wave: kFwdRows depth loads, then kFwdRows x C x 2 corner-pair gathers in flight
 
 template <int C>
 __global__ __launch_bounds__(kThreads) void warp_fwd_kernel(const float* __restrict__ K, const float* __restrict__ Kinv,
@@ -311,7 +314,10 @@ __device__ __forceinline__ void block_reduce12(float (&gM)[12], float* __restric
     }
 }
 
-constexpr int kBwdRows = 8;  // rows per wave: the 12-float pose-gradient wave reduction is paid once per 8 pixels
+#ifndef DS_BWD_ROWS
+#define DS_BWD_ROWS 8
+#endif
+constexpr int kBwdRows = DS_BWD_ROWS;  // rows per wave: the 12-float pose-gradient wave reduction is paid once per 8 pixels
 
 template <int C>
 __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restrict__ K, const float* __restrict__ Kinv,
