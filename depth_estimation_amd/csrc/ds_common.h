@@ -357,7 +357,7 @@ __device__ __forceinline__ void target_stats(float ay, float ayy, TgtStats& t) {
     t.sy_raw = div9(ayy) - t.my2;
 }
 
-struct SsimOut { float mx, sx, sxy, n, dd, v; };
+struct SsimOut { float mx, sx, sxy, n, dd, v, rdd; };  // rdd = refined 1/dd (by-product of the exact n/dd)
 
 __device__ __forceinline__ void ssim_from_sums(float ax, float axx, float axy, const TgtStats& t, SsimOut& o) {
     o.mx = div9(ax);
@@ -368,7 +368,8 @@ __device__ __forceinline__ void ssim_from_sums(float ax, float axx, float axy, c
     // (2*mx)*my == 2*(mx*my) and 2*s+C rounds once either way: the doublings are exact
     o.n = fmaf(2.0f, mxy, kC1) * fmaf(2.0f, o.sxy, kC2);
     o.dd = ((mx2 + t.my2) + kC1) * ((o.sx + t.sy_raw) + kC2);
-    o.v = (1.0f - div_noscale(o.n, o.dd)) * 0.5f;
+    o.rdd = rcp_refined(o.dd);
+    o.v = (1.0f - div_by(o.n, o.dd, o.rdd)) * 0.5f;   // == div_noscale(n, dd)
 }
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }

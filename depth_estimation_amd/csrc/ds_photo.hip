@@ -506,7 +506,7 @@ struct Coef { float A, Bc, Cc; };
 
 // g_v = d loss / d v of this window & channel (0 when the clamp blocked it)
 __device__ __forceinline__ Coef ssim_coefs(const SsimOut& so, const TgtStats& ts, float g_v) {
-    const float rdd = 1.0f / so.dd;
+    const float rdd = so.rdd;  // within 1 ulp of 1/dd: the gradient needs no more
     const float g_n = -0.5f * g_v * rdd;
     const float g_dd = -g_n * so.n * rdd;
     const float mx2 = so.mx * so.mx;
@@ -537,177 +537,205 @@ struct PhotoBwdParams {
     float* g_preds;         // (B, S_total, 3, H, W) offset like preds
 };
 
-template <int S>
-struct BwdState {
-    float X[S][3][3];
-    float Y[3][3];
-    float GW[3];            // per-pixel weight d loss / d out(p), by slot
-    int AM[3];              // aux byte, by slot
-    float ACC[3][S][3][3];  // [slot of output row][s][c][A,B,C]
-};
+// One wave = one colour channel of one band of 64 adjacent columns (62 of them outputs: a pixel's gradient needs the
+// windows one column to either side) walking down a row chunk (two lead-in rows that only feed the window sums, one
+// more window row above and below the chunk's outputs).  The channels are independent in the backward, so the waves
+// of a workgroup are four unrelated units: no barrier.  Two neighbour exchanges per row ride on the LDS pipe (a
+// wave's LDS instructions execute in order; no other wave touches its rows):
+//   * the raw values of the next row (as in the forward): L, C, R of every plane for the rolling window sums;
+//   * the window's tap coefficients, masked per source: the horizontal part of the 3x3 spread.
+// The vertical part of the spread keeps the horizontally spread coefficients of the last two window rows.
+// The forward's intermediates (window sums -> SSIM -> clamp decision) are recomputed with the forward's own code and
+// rounding; only the argmin source of a window gets gradient, so its sums are selected before the SSIM formula.
+template <int S, bool FUSED>
+__global__ __launch_bounds__(64 * kWaves, S >= 4 ? 3 : 4) void photo_bwd_kernel(PhotoBwdParams P) {
+    constexpr int NP = 1 + S;  // raw planes of this channel: target, then the S preds
+    constexpr int NK = 3 * S;  // masked tap coefficients: (A, B, C) per source
+    __shared__ float lds_raw[kWaves][NP][kLdsRow];
+    __shared__ float lds_k[kWaves][NK][kLdsRow];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int unit = xcd_remap(blockIdx.x, gridDim.x) * kWaves + wave;
+    if (unit >= P.B * P.nby * P.nbx * 3) return;
+    const int c = unit % 3, u1 = unit / 3, bx = u1 % P.nbx, u2 = u1 / P.nbx, by = u2 % P.nby, b = u2 / P.nby;
+    const int H = P.H, W = P.W;
+    const int y0 = by * P.RB, yend = min(y0 + P.RB, H);
+    const int c0 = bx * 62, col = c0 - 1 + lane;  // lane l holds column c0-1+l; outputs are lanes 1..62
+    const size_t HW = (size_t)H * W;
+    const unsigned uHW = (unsigned)HW;
+    const unsigned cl = (unsigned)reflect_idx(col, W) * 4u;
+    const unsigned ch = (unsigned)reflect_idx(lane < 32 ? c0 - 2 : c0 + 63, W) * 4u;
+    const bool edge = lane == 0 || lane == 63;
+    const int pad_slot = lane == 0 ? 0 : 65;
+    const bool col_exists = col >= 0 && col < W;
+    const bool lane_out = lane >= 1 && lane <= 62 && col < W;
+    const float wL = col == 1 ? 2.0f : 1.0f, wR = col == W - 2 ? 2.0f : 1.0f;  // reflect-pad adjoint, see above
+    const rsrc_t tp = make_rsrc(P.target + (size_t)b * P.tgt_stride_b);
+    const rsrc_t pp = make_rsrc(P.preds + (size_t)b * P.pred_stride_b);
+    const rsrc_t wp = make_rsrc((FUSED ? P.idt : P.g_out) + (size_t)b * HW);
+    const rsrc_t ap = make_rsrc(P.aux + (size_t)b * HW);
+    const rsrc_t gp = make_rsrc(P.g_preds + (size_t)b * P.pred_stride_b);
+    const float gscale = FUSED ? P.g_sums[b] * P.inv_hw : 1.0f;
+    float (*lr)[kLdsRow] = lds_raw[wave];
+    float (*lk)[kLdsRow] = lds_k[wave];
 
-template <int S, int SLOT>
-__device__ __forceinline__ void bwd_place(BwdState<S>& st, const float (&nx)[S][3], const float (&ny)[3], float gw, int am) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        st.Y[c][SLOT] = ny[c];
-#pragma unroll
-        for (int s = 0; s < S; ++s) st.X[s][c][SLOT] = nx[s][c];
-    }
-    st.GW[SLOT] = gw;
-    st.AM[SLOT] = am;
-}
-
-// coefficients of window row M (rows T,M,Bt present), spread horizontally, accumulated into the three
-// output rows it touches: Bt-slot row (initialised, weight wU), M-slot row (+=), T-slot row (+= weight wD).
-template <int S, int T, int M, int Bt>
-__device__ __forceinline__ void bwd_window(BwdState<S>& st, bool win_exists, int s_offset, float wL, float wR, float wU_next,
-                                           float wD_prev) {
-    const int idx = (st.AM[M] & 0x1f) - s_offset;  // argmin source of this window, relative to this launch's first
-    const float ge = win_exists ? st.GW[M] * (1.0f / 3.0f) : 0.0f;  // d loss / d e_c of this window
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float ay, ayy;
-        win_target(st.Y[c][T], st.Y[c][M], st.Y[c][Bt], ay, ayy);
-        TgtStats ts;
-        target_stats(ay, ayy, ts);
-        const float gv_c = 0.85f * ge;
-        // window sums of every source, then ONE SSIM + coefficient evaluation: only the argmin source of this
-        // window receives gradient, so its sums are selected per lane before the formula
-        float ax[S], axx[S], axy[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-            win_pair(st.X[s][c][T], st.X[s][c][M], st.X[s][c][Bt], st.Y[c][T], st.Y[c][M], st.Y[c][Bt], ax[s], axx[s], axy[s]);
-        float bx = ax[0], bxx = axx[0], bxy = axy[0];
-#pragma unroll
-        for (int s = 1; s < S; ++s) {
-            const bool is = idx == s;
-            bx = is ? ax[s] : bx;
-            bxx = is ? axx[s] : bxx;
-            bxy = is ? axy[s] : bxy;
-        }
-        SsimOut so;
-        ssim_from_sums(bx, bxx, bxy, ts, so);
-        // clamp passes the gradient iff 0 <= v <= 1 (so.v is recomputed bit-identically to the forward)
-        const bool live = idx >= 0 && idx < S && so.v >= 0.0f && so.v <= 1.0f;
-        const Coef k = ssim_coefs(so, ts, live ? gv_c : 0.0f);
+    struct Row { float v[NP], h[NP], gw; int am; };
+    auto issue = [&](int r, Row& o) {
+        const unsigned ro = (unsigned)(reflect_idx(r, H) * W);
+        o.v[0] = buf_load_f32(tp, cl, c * uHW + ro);
+        o.h[0] = buf_load_f32(tp, ch, c * uHW + ro);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const bool is = idx == s;
-            float hA, hB, hC;
-            spread3(is ? k.A : 0.0f, is ? k.Bc : 0.0f, is ? k.Cc : 0.0f, wL, wR, hA, hB, hC);
-            st.ACC[Bt][s][c][0] = wU_next * hA;
-            st.ACC[Bt][s][c][1] = wU_next * hB;
-            st.ACC[Bt][s][c][2] = wU_next * hC;
-            st.ACC[M][s][c][0] += hA;
-            st.ACC[M][s][c][1] += hB;
-            st.ACC[M][s][c][2] += hC;
-            st.ACC[T][s][c][0] = fmaf(wD_prev, hA, st.ACC[T][s][c][0]);
-            st.ACC[T][s][c][1] = fmaf(wD_prev, hB, st.ACC[T][s][c][1]);
-            st.ACC[T][s][c][2] = fmaf(wD_prev, hC, st.ACC[T][s][c][2]);
+            o.v[1 + s] = buf_load_f32(pp, cl, (s * 3 + c) * uHW + ro);
+            o.h[1 + s] = buf_load_f32(pp, ch, (s * 3 + c) * uHW + ro);
         }
+        o.gw = buf_load_f32(wp, cl, ro);
+        o.am = buf_load_u8(ap, cl >> 2, ro);
+    };
+    auto exchange_raw = [&](const Row& o, float (&L)[NP], float (&R)[NP]) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) lr[p][lane + 1] = o.v[p];
+        if (edge) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) lr[p][pad_slot] = o.h[p];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            L[p] = lr[p][lane];
+            R[p] = lr[p][lane + 2];
+        }
+    };
+
+    Roll Sy{0.f, 0.f}, Syy{0.f, 0.f}, Sx[S], Sxx[S], Sxy[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) Sx[s] = Sxx[s] = Sxy[s] = Roll{0.f, 0.f};
+    // per-lane values of the two rows before the newest one: [0] = row r-1 (window row), [1] = row r-2 (output row)
+    float pv[2][NP], pgw[2] = {0.f, 0.f};
+    int pam[2] = {0, 0};
+    float Hs[2][NK];  // horizontally spread coefficients of window rows j-1 ([0]) and j-2 ([1])
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) pv[i][p] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) Hs[i][k] = 0.f;
     }
-}
 
-template <int S, bool FUSED>
-__global__ __launch_bounds__(64 * kWaves) void photo_bwd_kernel(PhotoBwdParams P) {
-    const BandGeom g = band_geom<2>(P.B, P.H, P.W, P.nbx, P.nby, P.RB);
-    if (!g.active) return;
-    const unsigned cl = (unsigned)g.cl * 4u;  // lane's column byte offset: the only per-lane part of a load address
-    const int H = P.H, W = P.W;
-    const size_t HW = (size_t)H * W;
-    const rsrc_t tp = make_rsrc(P.target + (size_t)g.b * P.tgt_stride_b);
-    const rsrc_t pp = make_rsrc(P.preds + (size_t)g.b * P.pred_stride_b);
-    const unsigned uHW = (unsigned)HW;
-    float* gp = P.g_preds + (size_t)g.b * P.pred_stride_b + g.col;
-    const rsrc_t wp = make_rsrc((FUSED ? P.idt : P.g_out) + (size_t)g.b * HW);
-    const rsrc_t ap = make_rsrc(P.aux + (size_t)g.b * HW);
-    const float gscale = FUSED ? P.g_sums[g.b] * P.inv_hw : 1.0f;
-    const bool col_exists = g.col >= 0 && g.col < W;
-    const bool lane_out = g.lane >= 2 && g.lane <= 61 && g.col < W;
-    const float wL = g.col == 1 ? 2.0f : 1.0f, wR = g.col == W - 2 ? 2.0f : 1.0f;
+    Row pend;
+    float cL[NP], cC[NP], cR[NP], cgw;
+    int cam;
+    issue(y0 - 2, pend);
+    exchange_raw(pend, cL, cR);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) cC[p] = pend.v[p];
+    cgw = pend.gw;
+    cam = pend.am;
+    issue(y0 - 1, pend);
 
-    BwdState<S> st;
-    float nx[S][3], ny[3], ngw;
-    int nam;
-    auto load_row = [&](int r) {
-        const unsigned ro = (unsigned)(reflect_idx(r, H) * W);
+    // row r arrives: window row j = r-1 completes (from r = y0 on), output row t = r-2 completes (from r = y0+2 on)
+    for (int r = y0 - 2; r <= yend + 1; ++r) {
+        float nL[NP], nC[NP], nR[NP];
+        exchange_raw(pend, nL, nR);  // row r+1
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            ny[c] = buf_load_f32(tp, cl, c * uHW + ro);
+        for (int p = 0; p < NP; ++p) nC[p] = pend.v[p];
+        const float ngw_raw = pend.gw;
+        const int nam = pend.am;
+        issue(r + 2, pend);
+
+        const float yL = cL[0], yC = cC[0], yR = cR[0];
+        const float ay = roll(Sy, yL, yC, yR);
+        const float ayy = roll(Syy, yL * yL, yC * yC, yR * yR);
+        float ax[S], axx[S], axy[S];
 #pragma unroll
-            for (int s = 0; s < S; ++s) nx[s][c] = buf_load_f32(pp, cl, (s * 3 + c) * uHW + ro);
+        for (int s = 0; s < S; ++s) {
+            const float xL = cL[1 + s], xC = cC[1 + s], xR = cR[1 + s];
+            ax[s] = roll(Sx[s], xL, xC, xR);
+            axx[s] = roll(Sxx[s], xL * xL, xC * xC, xR * xR);
+            axy[s] = roll(Sxy[s], xL * yL, xC * yC, xR * yR);
         }
-        const float w = buf_load_f32(wp, cl, ro);
-        ngw = FUSED ? gscale / expf(w + 1e-6f) : w;
-        nam = buf_load_u8(ap, cl >> 2, ro);
-    };
-    // emit output row t held in slot TS (values X/Y/GW/AM of row t live in the same slot)
-    auto emit = [&](int t, int /*unused*/, const float (&acc)[S][3][3], const float (&X)[S][3], const float (&Y)[3], float gw,
-                    int am) {
-        if (!lane_out) return;
-        const float ge = gw * (1.0f / 3.0f);
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float gg = fmaf(Y[c], acc[s][c][2], fmaf(X[s][c], acc[s][c][1], acc[s][c][0]));
-                const float diff = Y[c] - X[s][c];
-                const float sgn = diff > 0.f ? -1.0f : (diff < 0.f ? 1.0f : 0.0f);
-                if ((am & 0x1f) == s + P.s_offset) gg = fmaf(0.15f * ge, sgn, gg);
-                gp[(s * 3 + c) * HW + (size_t)t * W] = gg;
-            }
-    };
-    auto row_of = [&](int slot, float (&X)[S][3], float (&Y)[3]) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            Y[c] = st.Y[c][slot];
-#pragma unroll
-            for (int s = 0; s < S; ++s) X[s][c] = st.X[s][c][slot];
-        }
-    };
-    auto wU = [&](int t) { return t == 1 ? 2.0f : 1.0f; };
-    auto wD = [&](int t) { return t == H - 2 ? 2.0f : 1.0f; };
+        // gradient weight of the newest row's pixels: d loss / d out(p)
+        const float gw_new = FUSED ? gscale * __builtin_amdgcn_exp2f((cgw + 1e-6f) * -1.4426950408889634f) : cgw;
 
-    // rows y0-2, y0-1 -> slots 0,1; zero the accumulators that window row y0-1 will add into
-    load_row(g.y0 - 2);
-    bwd_place<S, 0>(st, nx, ny, ngw, nam);
-    load_row(g.y0 - 1);
-    bwd_place<S, 1>(st, nx, ny, ngw, nam);
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) st.ACC[0][s][c][k] = st.ACC[1][s][c][k] = 0.f;
-    load_row(g.y0);
-    float X[S][3], Y[3];
-    // step for new row r (slot SL): window row j = r-1 (slot M), output row t = r-2 (slot T) completes
-    const int rlast = g.yend + 1;  // output row t completes when row t+2 has arrived
-    for (int r = g.y0; r <= rlast; r += 3) {
-        {   // r in slot 2; window j=r-1 in slot 1; output t=r-2 in slot 0
-            bwd_place<S, 2>(st, nx, ny, ngw, nam);
-            load_row(r + 1);
+        if (r >= y0) {
+            // ---- window row j = r-1: coefficients of its taps, masked per source, spread horizontally
             const int j = r - 1;
-            bwd_window<S, 0, 1, 2>(st, col_exists && j >= 0 && j < H, P.s_offset, wL, wR, wU(r), wD(r - 2));
-            if (r - 2 >= g.y0) { row_of(0, X, Y); emit(r - 2, 0, st.ACC[0], X, Y, st.GW[0], st.AM[0]); }
+            const bool win_exists = col_exists && j >= 0 && j < H;
+            const int idx = (pam[0] & 0x1f) - P.s_offset;  // argmin source of this window, relative to this launch
+            TgtStats ts;
+            target_stats(ay, ayy, ts);
+            float bx_ = ax[0], bxx = axx[0], bxy = axy[0];
+#pragma unroll
+            for (int s = 1; s < S; ++s) {
+                const bool is = idx == s;
+                bx_ = is ? ax[s] : bx_;
+                bxx = is ? axx[s] : bxx;
+                bxy = is ? axy[s] : bxy;
+            }
+            SsimOut so;
+            ssim_from_sums(bx_, bxx, bxy, ts, so);
+            // clamp passes the gradient iff 0 <= v <= 1 (so.v is recomputed bit-identically to the forward)
+            const bool live = win_exists && idx >= 0 && idx < S && so.v >= 0.0f && so.v <= 1.0f;
+            const Coef k = ssim_coefs(so, ts, live ? pgw[0] * (0.85f / 3.0f) : 0.0f);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const bool is = idx == s;
+                lk[3 * s + 0][lane + 1] = is ? k.A : 0.0f;
+                lk[3 * s + 1][lane + 1] = is ? k.Bc : 0.0f;
+                lk[3 * s + 2][lane + 1] = is ? k.Cc : 0.0f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float Hn[NK];
+#pragma unroll
+            for (int q = 0; q < NK; ++q) {
+                const float kc = (idx == q / 3) ? (q % 3 == 0 ? k.A : (q % 3 == 1 ? k.Bc : k.Cc)) : 0.0f;
+                Hn[q] = fmaf(wR, lk[q][lane + 2], fmaf(wL, lk[q][lane], kc));
+            }
+            // ---- output row t = r-2: windows t-1 (Hs[1]), t (Hs[0]), t+1 (Hn), reflect-pad adjoint weights
+            const int t = r - 2;
+            if (t >= y0) {
+                const float wU = t == 1 ? 2.0f : 1.0f, wD = t == H - 2 ? 2.0f : 1.0f;
+                const float ge = pgw[1] * (1.0f / 3.0f);
+                const float Y = pv[1][0];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float gA = fmaf(wD, Hn[3 * s + 0], fmaf(wU, Hs[1][3 * s + 0], Hs[0][3 * s + 0]));
+                    const float gB = fmaf(wD, Hn[3 * s + 1], fmaf(wU, Hs[1][3 * s + 1], Hs[0][3 * s + 1]));
+                    const float gC = fmaf(wD, Hn[3 * s + 2], fmaf(wU, Hs[1][3 * s + 2], Hs[0][3 * s + 2]));
+                    const float X = pv[1][1 + s];
+                    float gg = fmaf(Y, gC, fmaf(X, gB, gA));
+                    const float diff = Y - X;
+                    const float sgn = diff > 0.f ? -1.0f : (diff < 0.f ? 1.0f : 0.0f);
+                    if ((pam[1] & 0x1f) == s + P.s_offset) gg = fmaf(0.15f * ge, sgn, gg);
+                    if (lane_out) buf_store_f32(gg, gp, (unsigned)col * 4u, ((s * 3 + c) * uHW + (unsigned)(t * W)) * 4u);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NK; ++q) {
+                Hs[1][q] = Hs[0][q];
+                Hs[0][q] = Hn[q];
+            }
         }
-        if (r + 1 > rlast) break;
-        {   // r+1 in slot 0; window in slot 2; output in slot 1
-            bwd_place<S, 0>(st, nx, ny, ngw, nam);
-            load_row(r + 2);
-            const int j = r;
-            bwd_window<S, 1, 2, 0>(st, col_exists && j >= 0 && j < H, P.s_offset, wL, wR, wU(r + 1), wD(r - 1));
-            if (r - 1 >= g.y0) { row_of(1, X, Y); emit(r - 1, 0, st.ACC[1], X, Y, st.GW[1], st.AM[1]); }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            pv[1][p] = pv[0][p];
+            pv[0][p] = cC[p];
+            cL[p] = nL[p];
+            cC[p] = nC[p];
+            cR[p] = nR[p];
         }
-        if (r + 2 > rlast) break;
-        {   // r+2 in slot 1; window in slot 0; output in slot 2
-            bwd_place<S, 1>(st, nx, ny, ngw, nam);
-            load_row(r + 3);
-            const int j = r + 1;
-            bwd_window<S, 2, 0, 1>(st, col_exists && j >= 0 && j < H, P.s_offset, wL, wR, wU(r + 2), wD(r));
-            { row_of(2, X, Y); emit(r, 0, st.ACC[2], X, Y, st.GW[2], st.AM[2]); }
-        }
+        pgw[1] = pgw[0];
+        pgw[0] = gw_new;
+        pam[1] = pam[0];
+        pam[0] = cam;
+        cgw = ngw_raw;
+        cam = nam;
     }
 }
 
@@ -890,6 +918,24 @@ int launch_photo_fwd(int S, PhotoFwdParams P, Geom* geom_out, hipStream_t st) {
     return DS_OK;
 }
 
+// Backward loss kernel: units of (band of 62 output columns, row chunk, channel), four to a workgroup.  Chunks cost
+// about three rows of lead-in/lead-out, so at least 16 rows; otherwise about eight rounds of workgroups (see
+// make_fwd_lds_geom).  nblocks counts workgroups, nwaves units.
+inline Geom make_bwd_geom(int B, int H, int W) {
+    Geom g;
+    g.nbx = (W + 61) / 62;
+    const long long capacity = (long long)simd_count() * 4;  // units resident at once (four waves per SIMD)
+    const long long per_chunk = (long long)B * g.nbx * 3;
+    long long nby = (8 * capacity + per_chunk - 1) / per_chunk;
+    const int max_nby = H / 16 > 1 ? H / 16 : 1;
+    if (nby > max_nby) nby = max_nby;
+    g.RB = (H + (int)nby - 1) / (int)nby;
+    g.nby = (H + g.RB - 1) / g.RB;
+    g.nwaves = B * g.nbx * g.nby * 3;
+    g.nblocks = (g.nwaves + kWaves - 1) / kWaves;
+    return g;
+}
+
 template <bool FUSED>
 int launch_photo_bwd(int S, const PhotoBwdParams& P, int nblocks, hipStream_t st) {
     dim3 g(nblocks), b(64 * kWaves);
@@ -953,7 +999,7 @@ int ds_reprojection_loss_bwd(const float* preds, const float* targets, long long
                              const float* g_out, const uint8_t* aux, int B, int S, int H, int W, float* g_preds,
                              void* stream) {
     if (!preds || !targets || !g_out || !aux || !g_preds || bad_dims(B, S, H, W) || S > 32) return DS_ERR_INVALID_ARG;
-    const Geom g = make_geom(B, H, W, 2, 60, 1.0);
+    const Geom g = make_bwd_geom(B, H, W);
     const long long HW = (long long)H * W;
     PhotoBwdParams P{};
     P.pred_stride_b = (long long)S * 3 * HW;
@@ -1009,7 +1055,7 @@ int ds_fused_loss_bwd(const float* warped, const float* target, const float* idt
                       const float* g_sums, int B, int S, int H, int W, float* g_warped, void* stream) {
     if (!warped || !target || !idt_loss || !aux || !g_sums || !g_warped || bad_dims(B, S, H, W)) return DS_ERR_INVALID_ARG;
     if (S > DS_MAX_SOURCES) return DS_ERR_UNSUPPORTED;
-    const Geom g = make_geom(B, H, W, 2, 60, 1.0);
+    const Geom g = make_bwd_geom(B, H, W);
     const long long HW = (long long)H * W;
     PhotoBwdParams P{};
     P.preds = warped; P.target = target; P.idt = idt_loss; P.g_sums = g_sums; P.aux = aux;
