@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--image-grad", action="store_true", help="also scatter the source-image gradient")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="sub-batches per step, each on its own HIP stream: the memory-bound warp kernels of one overlap "
                          "the VALU-bound loss kernels of the other (1 = whole batch on one stream)")
     args = ap.parse_args()
