@@ -111,7 +111,7 @@ constexpr int kLdsRow = 68;  // 64 columns + left/right halo column (+2 pad)
 constexpr int kFwdWaves = 4;
 
 template <int S, bool IDT>
-__global__ __launch_bounds__(64 * kFwdWaves, 4) void photo_fwd_kernel(PhotoFwdParams P) {
+__global__ __launch_bounds__(64 * kFwdWaves, (IDT ? 2 * S : S) > 4 ? 3 : 4) void photo_fwd_kernel(PhotoFwdParams P) {
     constexpr int G = IDT ? 2 * S : S;
     constexpr int NP = 1 + G;
     constexpr int kK = G <= 4 ? 4 : 2;  // rows per barrier (slab = 2 * kK * 3 * G * 256 B of LDS)
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * kFwdWaves, 4) void photo_fwd_kernel(PhotoFwdPa
 }
 
 // =====================================================================================================
-// forward, register-lean variant for many groups (S >= 3 with the identity groups): three raw rows per plane in
+// forward, register-lean variant for many groups (S = 4 with the identity groups, G = 8): three raw rows per plane in
 // registers, neighbours through DPP wave shifts folded into the adds, 62 useful columns per wave.  Same arithmetic,
 // same results; ~25 % slower per pixel than the LDS-exchange kernel above, but 3 registers per plane instead of 7.
 // =====================================================================================================
@@ -853,9 +853,9 @@ inline Geom make_geom(int B, int H, int W, int halo, int useful, double halo_row
 }
 
 // Forward loss kernels.  The channel-split LDS-exchange kernel (one 4-wave workgroup per band of 64 columns and row
-// chunk) is used wherever a wave's partial sums leave it below 128 VGPRs (G = groups per launch <= 4), the DPP kernel
-// (one wave per band of 62 useful columns) otherwise.
-inline bool fwd_uses_lds(int S, bool idt) { return (idt ? 2 * S : S) <= 4; }
+// chunk) is used wherever a wave's partial sums fit the register file without spilling (G = groups per launch <= 6:
+// 111 VGPRs at G = 4, 154 at G = 6), the DPP kernel (one wave per band of 62 useful columns) for G = 8.
+inline bool fwd_uses_lds(int S, bool idt) { return (idt ? 2 * S : S) <= 6; }
 
 // Row chunking of the channel-split kernel: one workgroup per (band, row chunk); a CU holds four of them (VGPR
 // limit), the chip 4 * CUs at a time.  A chunk costs its rows plus about one row of lead-in, so chunks should be long;
@@ -907,12 +907,10 @@ int launch_photo_fwd(int S, PhotoFwdParams P, Geom* geom_out, hipStream_t st) {
             case 4: if (IDT) hipLaunchKernelGGL((photo_fwd_kernel<2, true>), g, b, 0, st, P);
                     else hipLaunchKernelGGL((photo_fwd_kernel<4, false>), g, b, 0, st, P);
                     break;
+            case 6: hipLaunchKernelGGL((photo_fwd_kernel<3, true>), g, b, 0, st, P); break;
         }
     } else {
-        switch (S) {  // IDT only
-            case 3: hipLaunchKernelGGL((photo_fwd_dpp_kernel<3, true>), g, b, 0, st, P); break;
-            case 4: hipLaunchKernelGGL((photo_fwd_dpp_kernel<4, true>), g, b, 0, st, P); break;
-        }
+        hipLaunchKernelGGL((photo_fwd_dpp_kernel<4, true>), g, b, 0, st, P);  // S = 4 with identity groups only
     }
     DS_CHECK_LAUNCH();
     return DS_OK;
