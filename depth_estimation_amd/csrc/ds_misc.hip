@@ -315,6 +315,40 @@ inline bool fill_planes(Planes& pl, const double* depths_host, int D) {
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Input pipeline to the device: what torchvision's to_tensor does to the resized PIL frame
+// (dataset.py:51,110): uint8 HWC -> float32 CHW, value / 255 (true divide).  Four pixels per thread: 12 interleaved
+// bytes in, one float4 per channel out.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void ingest_u8_kernel(const uint8_t* __restrict__ frames, int HW,
+                                                             float* __restrict__ out) {
+    const int n = blockIdx.y;
+    const int q = blockIdx.x * kThreads + threadIdx.x;  // group of four pixels
+    const int p0 = q * 4;
+    if (p0 >= HW) return;
+    const uint8_t* in = frames + (size_t)n * HW * 3 + (size_t)p0 * 3;
+    float* o = out + (size_t)n * 3 * HW + p0;
+    if (p0 + 4 <= HW && (HW & 3) == 0) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(in);  // 12-byte groups of a 4-byte aligned base
+        const uint32_t a = w[0], b = w[1], c = w[2];
+        const uint8_t v[12] = {(uint8_t)a, (uint8_t)(a >> 8), (uint8_t)(a >> 16), (uint8_t)(a >> 24),
+                               (uint8_t)b, (uint8_t)(b >> 8), (uint8_t)(b >> 16), (uint8_t)(b >> 24),
+                               (uint8_t)c, (uint8_t)(c >> 8), (uint8_t)(c >> 16), (uint8_t)(c >> 24)};
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float4 f;
+            f.x = (float)v[ch] / 255.0f;
+            f.y = (float)v[3 + ch] / 255.0f;
+            f.z = (float)v[6 + ch] / 255.0f;
+            f.w = (float)v[9 + ch] / 255.0f;
+            *reinterpret_cast<float4*>(o + (size_t)ch * HW) = f;
+        }
+    } else {
+        for (int i = 0; i < 4 && p0 + i < HW; ++i)
+            for (int ch = 0; ch < 3; ++ch) o[(size_t)ch * HW + i] = (float)in[3 * i + ch] / 255.0f;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -413,6 +447,16 @@ int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, fl
     DS_CHECK_LAUNCH();
     hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, B, nb,
                        1.0 / ((double)H * W), out);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_ingest_u8(const uint8_t* frames, int N, int H, int W, float* out, void* stream) {
+    if (!frames || !out || N <= 0 || N > 65535 || H <= 0 || W <= 0 || (long long)H * W > (1ll << 30)) return DS_ERR_INVALID_ARG;
+    if (((uintptr_t)frames & 3) || ((uintptr_t)out & 15)) return DS_ERR_INVALID_ARG;
+    const int HW = H * W, groups = (HW + 3) / 4;
+    hipLaunchKernelGGL(ingest_u8_kernel, dim3((groups + kThreads - 1) / kThreads, N), dim3(kThreads), 0, (hipStream_t)stream,
+                       frames, HW, out);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

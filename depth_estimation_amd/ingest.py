@@ -1,0 +1,27 @@
+"""Input pipeline to the device: the last step of the reference's loaders, on the GPU.
+
+`dataset.py:51,110` does `tf.to_tensor(tf.resize(img, (192, 640)))` per frame on the host and then `.to(device)`
+(`dataset.py:55,113`) -- 12 B per pixel over PCIe.  Here the resized PIL frame travels as uint8 (3 B per pixel) and
+`to_tensor` (uint8 HWC -> float32 CHW, value / 255) runs on the device.  The PIL resize stays on the host.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+def to_tensor(frames: torch.Tensor) -> torch.Tensor:
+    """frames (N,H,W,3) or (H,W,3) uint8 on the GPU -> (N,3,H,W) / (3,H,W) float32 in [0,1]; bit-identical to
+    torchvision.transforms.functional.to_tensor on the same pixels."""
+    if frames.dtype != torch.uint8 or not frames.is_cuda:
+        raise RuntimeError(f"to_tensor expects a uint8 CUDA tensor, got {frames.dtype} on {frames.device}")
+    single = frames.dim() == 3
+    x = frames.unsqueeze(0) if single else frames
+    if x.dim() != 4 or x.shape[-1] != 3:
+        raise RuntimeError(f"expected (N,H,W,3) or (H,W,3), got {tuple(frames.shape)}")
+    x = x.contiguous()
+    n, h, w, _ = x.shape
+    out = torch.empty(n, 3, h, w, dtype=torch.float32, device=x.device)
+    L.check(L.lib().ds_ingest_u8(x.data_ptr(), n, h, w, out.data_ptr(), L.stream()), "ds_ingest_u8")
+    return out[0] if single else out

@@ -141,6 +141,11 @@ size_t ds_metrics_workspace_bytes(int B, int H, int W);
 int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, float* out, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* Input pipeline to the device: torchvision.transforms.functional.to_tensor on the resized frame (dataset.py:51,110):
+ * frames (N,H,W,3) uint8 interleaved -> out (N,3,H,W) fp32 = value / 255.  The PIL resize itself stays on the host.
+ * frames 4-byte aligned, out 16-byte aligned. */
+int ds_ingest_u8(const uint8_t* frames, int N, int H, int W, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

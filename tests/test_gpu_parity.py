@@ -5,6 +5,8 @@ Bars (BASELINE.json north_star): bit-exact for every forward stage without a tra
 the stated 1e-5); 1e-5 max-abs on anything that goes through expf; 1e-4 relative-to-max on gradients and
 scalar metrics.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -278,6 +280,27 @@ def test_smoothness(de, oracle):
         assert abs(float(reg) - float(d["reg"])) < 1e-4 * abs(float(d["reg"]))            # metrics.py:75-97
         reg.backward()
         assert rel_to_max(N(dep.grad), d["g_depth_reg"]) < 1e-4
+
+
+def test_ingest_u8_matches_to_tensor(de):
+    """to_tensor of the resized frames on the device == the float tensors the reference computed from the
+    same uint8 frames (dataset.py:51; fixtures real_*_frames_u8.npz and the src/target of real_*.npz), bit-exact;
+    plus a ragged size (H*W not a multiple of 4) against value/255 and the (H,W,3) single-frame form."""
+    for name in ("real_192x640", "real_48x160"):
+        fr = np.load(os.path.join(os.path.dirname(__file__), "golden", name + "_frames_u8.npz"))["frames"]
+        d = load_golden(name)
+        got = N(de.ingest.to_tensor(torch.from_numpy(fr).to(DEV)))
+        assert got.shape == (fr.shape[0], 3) + fr.shape[1:3]
+        assert np.array_equal(got[:3], d["src"]) and np.array_equal(got[3], d["target"])
+    g = torch.Generator().manual_seed(5)
+    odd = torch.randint(0, 256, (2, 7, 9, 3), generator=g, dtype=torch.uint8)
+    want = (odd.float() / 255).permute(0, 3, 1, 2).numpy()
+    assert np.array_equal(N(de.ingest.to_tensor(odd.to(DEV))), want)
+    assert np.array_equal(N(de.ingest.to_tensor(odd[1].to(DEV))), want[1])
+    with pytest.raises(RuntimeError):
+        de.ingest.to_tensor(odd)                      # CPU tensor
+    with pytest.raises(RuntimeError):
+        de.ingest.to_tensor(odd.to(DEV).float())      # wrong dtype
 
 
 def test_rejects_cpu_tensors_and_bad_shapes(de):
