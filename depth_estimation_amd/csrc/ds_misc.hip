@@ -4,6 +4,7 @@
 // synthesis.depth_from_costs (synthesis.py:119-138), metrics.regularization_term (metrics.py:75-97),
 // metrics.rmse/rmsle/abs_rel/sq_rel (metrics.py:100-153).
 #include "ds_common.h"
+#include "ds_warp_dev.h"
 #include "depthsynth.h"
 
 using namespace ds;
@@ -86,50 +87,102 @@ __global__ __launch_bounds__(kThreads) void depth_from_costs_kernel(const float*
     depth[(size_t)n * HW + p] = index_to_depth(num / den, D, sid);
 }
 
-// fused a4+a5+a6: one thread per (source, pixel), online softmin over the planes; nothing materialised
+// fused a4+a5+a6: one thread per (source, pixel), online softmin over the planes; nothing materialised.
+// In a real train step this is 20x the warped pixels of the loss path (S x 80 planes at quarter resolution), and it is
+// VALU-bound, so the per-plane work is written for instruction count like the warp kernels (ds_warp_dev.h): a wave
+// owns 64 adjacent columns of one row (no integer division), the ray K^-1 [x,y,1] is formed once per pixel, the
+// exact divides share one refined reciprocal per denominator or take it from the host, the border cases of the
+// bilinear gather select weights once per plane instead of texel values per channel, buffer loads carry the image
+// base in an SGPR descriptor, and the online softmin needs one exponential per plane instead of two.
+template <int C>
 __global__ __launch_bounds__(kThreads) void plane_sweep_depth_kernel(const float* __restrict__ K,
                                                                      const float* __restrict__ Kinv,
                                                                      const float* __restrict__ pose, Planes planes, int D,
                                                                      const float* __restrict__ src,
-                                                                     const float* __restrict__ target, int C, int Hs, int Ws,
-                                                                     int H, int W, int sid, float* __restrict__ depth) {
+                                                                     const float* __restrict__ target, int Cdyn, WarpGeom G,
+                                                                     int sid, float* __restrict__ depth) {
     const int n = blockIdx.y;
-    const int HW = H * W;
-    const int p = blockIdx.x * kThreads + threadIdx.x;
-    if (p >= HW) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int bx = blockIdx.x % G.nbx, by = blockIdx.x / G.nbx;
+    const int y = by * (kThreads / 64) + wave;
+    if (y >= G.H) return;
+    const int x = bx * 64 + lane, xc = min(x, G.W - 1);
+    const int Cc = C > 0 ? C : Cdyn;
+    const unsigned HW = (unsigned)(G.H * G.W), HsWs = (unsigned)(G.Hs * G.Ws);
     Cam cam;
     load_cam(cam, K, Kinv, pose + 12 * n);
-    const float* sp = src + (size_t)n * C * Hs * Ws;
-    const int y = p / W, x = p - y * W;
+    const rsrc_t sp = make_rsrc(src + (size_t)n * Cc * HsWs);
+    const rsrc_t tp = make_rsrc(target);
+    const unsigned po = (unsigned)xc * 4u, ro = (unsigned)(y * G.W);
+    // the ray of this pixel (synthesis.py:100), shared by all planes
+    float ray[3];
+    {
+        const float fx = (float)xc, fy = (float)y;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float acc = fx * cam.Kinv[3 * j + 0];
+            acc = fmaf(fy, cam.Kinv[3 * j + 1], acc);
+            ray[j] = fmaf(1.0f, cam.Kinv[3 * j + 2], acc);
+        }
+    }
+    float tg[C > 0 ? C : 1];
+    if (C > 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) tg[c] = buf_load_f32(tp, po, c * HW + ro);
+    }
     float run_min = INFINITY, den = 0.f, num = 0.f;
     for (int k = 0; k < D; ++k) {
-        Proj pr;
-        project_pixel(cam, (float)x, (float)y, planes.d[k], pr);
-        Samp s;
-        sample_setup(pr.u, pr.v, Hs, Ws, s);
-        Corners co;
-        corner_offsets(s, Hs, Ws, co);
+        const float d = planes.d[k];
+        float P[3], T[3], q[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) P[j] = ray[j] * d;                                   // synthesis.py:105
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                                                    // :108-109
+            float acc = P[0] * cam.M[4 * j + 0];
+            acc = fmaf(P[1], cam.M[4 * j + 1], acc);
+            acc = fmaf(P[2], cam.M[4 * j + 2], acc);
+            T[j] = fmaf(1.0f, cam.M[4 * j + 3], acc);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                                                    // :112
+            float acc = T[0] * cam.K[3 * j + 0];
+            acc = fmaf(T[1], cam.K[3 * j + 1], acc);
+            q[j] = fmaf(T[2], cam.K[3 * j + 2], acc);
+        }
+        const float z = (fabsf(q[2]) < 1e-6f) ? 1e-6f : q[2];                            // :113
+        const float rz = rcp_refined(z);
+        Tap t;
+        make_tap(div_by(q[0], z, rz), div_by(q[1], z, rz), G, t);                        // :114, :49-54
         float acc = 0.f;
-        for (int c = 0; c < C; ++c) {
-            float nw, ne, sw, se;
-            gather4(sp + (size_t)c * Hs * Ws, co, nw, ne, sw, se);
-            float a = fabsf(target[(size_t)c * HW + p] - bilinear(nw, ne, sw, se, s));
+        auto channel = [&](int c, float tv) {
+            const float2_t top = buf_load_f32x2(sp, t.o_top, c * HsWs * 4u);
+            const float2_t bot = buf_load_f32x2(sp, t.o_bot, c * HsWs * 4u);
+            float w = top.x * t.wa_t;
+            w = fmaf(top.y, t.wb_t, w);
+            w = fmaf(bot.x, t.wa_b, w);
+            w = fmaf(bot.y, t.wb_b, w);
+            const float a = fabsf(tv - w);                                               // metrics.py:14-18
             acc = (c == 0) ? a : acc + a;
+        };
+        if (C > 0) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) channel(c, tg[c]);
+        } else {
+            for (int c = 0; c < Cc; ++c) channel(c, buf_load_f32(tp, po, c * HW + ro));
         }
-        const float cst = (C == 3) ? div3(acc) : acc / (float)C;
+        const float cst = (C == 3) ? div3(acc) : acc / (float)Cc;
         const float e = expf(cst);
-        const float v = e * e - 1.0f;
-        if (v < run_min) {  // new minimum: rescale what has been accumulated so far
-            const float r = expf(v - run_min);  // exp(-inf) = 0 on the first plane
-            den *= r;
-            num *= r;
-            run_min = v;
-        }
-        const float w = expf(run_min - v);
-        den += w;
-        num = fmaf(w, (float)k, num);
+        const float v = e * e - 1.0f;                                                    // synthesis.py:127
+        // online softmin: with m = min(run_min, v) the old sums scale by exp(m - run_min), the new term by
+        // exp(m - v); one of the two factors is 1, the other exp(-|v - run_min|) (exp(-inf) = 0 on the first plane)
+        const float f = __builtin_amdgcn_exp2f(fabsf(v - run_min) * -1.4426950408889634f);
+        const bool lower = v < run_min;
+        const float so = lower ? f : 1.0f, sn = lower ? 1.0f : f;
+        den = fmaf(den, so, sn);
+        num = fmaf(num, so, sn * (float)k);
+        run_min = fminf(run_min, v);
     }
-    depth[(size_t)n * HW + p] = index_to_depth(num / den, D, sid);
+    if (x < G.W) depth[(size_t)n * HW + ro + x] = index_to_depth(num / den, D, sid);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -399,8 +452,14 @@ int ds_plane_sweep_depth(const float* K, const float* Kinv, const float* pose, c
     if (!K || !Kinv || !pose || !src || !target_small || !depth || bad_img(NS, C, H, W) || Hs < 2 || Ws < 2 ||
         !fill_planes(pl, depths_host, D))
         return DS_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(plane_sweep_depth_kernel, dim3(pix_blocks(H * W), NS), dim3(kThreads), 0, (hipStream_t)stream, K, Kinv,
-                       pose, pl, D, src, target_small, C, Hs, Ws, H, W, sid, depth);
+    const WarpGeom G = warp_geom(Hs, Ws, H, W);
+    dim3 grid(G.nbx * ((H + kThreads / 64 - 1) / (kThreads / 64)), NS), blk(kThreads);
+    if (C == 3)
+        hipLaunchKernelGGL(plane_sweep_depth_kernel<3>, grid, blk, 0, (hipStream_t)stream, K, Kinv, pose, pl, D, src,
+                           target_small, C, G, sid, depth);
+    else
+        hipLaunchKernelGGL(plane_sweep_depth_kernel<0>, grid, blk, 0, (hipStream_t)stream, K, Kinv, pose, pl, D, src,
+                           target_small, C, G, sid, depth);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

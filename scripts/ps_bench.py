@@ -1,0 +1,26 @@
+"""Timing of the fused plane sweep (train.py:49-59 for one target): NS sources 192x640 -> candidate depth 96x320, D=80."""
+import sys, os, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import depth_estimation_amd as de
+from depth_estimation_amd import ops
+dev = "cuda:0"
+NS = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+g = torch.Generator().manual_seed(0)
+src = torch.rand(NS, 3, 192, 640, generator=g).to(dev)
+tgt = torch.rand(3, 96, 320, generator=g).to(dev)
+K, Kinv = de.fused.intrinsics(320, 96)
+K, Kinv = K.to(dev), Kinv.to(dev)
+pose = ops.pose_from_vec((0.01 * torch.randn(NS, 6, generator=g)).to(dev)).contiguous()
+depths = np.exp(np.linspace(np.log(1.0), np.log(80.0), 80))
+for _ in range(5):
+    out = ops.plane_sweep_depth(K, Kinv, pose, depths, src, tgt, True)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+n = 50
+for _ in range(n):
+    out = ops.plane_sweep_depth(K, Kinv, pose, depths, src, tgt, True)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / n
+px = NS * 80 * 96 * 320
+print(f"plane sweep NS={NS}: {ms*1e3:.1f} us per call, {px/ms/1e6:.2f} Gpix/s (plane-warped pixels), checksum {float(out.sum()):.6f}")
