@@ -102,8 +102,10 @@ def build_problem(de, wl, dev, rank, image_grad, parts=1):
     independent sub-batches (own buffers, own workspaces), which the step launches on `parts` HIP streams."""
     scales = []
     for i in range(wl["scales"]):
-        for j in range(parts):
-            b = wl["B"] // parts + (1 if j < wl["B"] % parts else 0)
+        # small pyramid levels are launch-bound: splitting them only adds launches
+        lvl_parts = parts if wl["B"] * (wl["H"] >> i) * (wl["W"] >> i) >= (1 << 20) else 1
+        for j in range(lvl_parts):
+            b = wl["B"] // lvl_parts + (1 if j < wl["B"] % lvl_parts else 0)
             if b > 0:
                 scales.append(Scale(de, b, wl["S"], wl["H"] >> i, wl["W"] >> i, dev, 1000 * rank + 10 * i + j, image_grad))
     return scales
@@ -177,7 +179,8 @@ def main():
     parts = 1 if args.graph else max(1, min(args.streams, wl["B"]))
     scales = build_problem(de, wl, dev, rank, args.image_grad, parts)
     st = torch.cuda.current_stream().cuda_stream
-    side_streams = [torch.cuda.Stream() for _ in range(parts)] if parts > 1 else []
+    # one stream per (pyramid level, sub-batch): the levels are independent calls too (BASELINE config 3)
+    side_streams = [torch.cuda.Stream() for _ in range(len(scales))] if parts > 1 else []
 
     def step():
         if parts == 1:
@@ -188,12 +191,11 @@ def main():
         for sc in scales:
             if sc.g_src is not None:
                 sc.g_src.zero_()
-        for lvl in range(0, len(scales), parts):
-            for name in ("warp_fwd", "loss_fwd", "loss_bwd", "warp_bwd"):
-                for j, sc in enumerate(scales[lvl:lvl + parts]):
-                    rc = sc.calls[name](side_streams[j].cuda_stream)
-                    if rc != 0:
-                        sc.L.check(rc, name)
+        for name in ("warp_fwd", "loss_fwd", "loss_bwd", "warp_bwd"):
+            for j, sc in enumerate(scales):
+                rc = sc.calls[name](side_streams[j].cuda_stream)
+                if rc != 0:
+                    sc.L.check(rc, name)
 
     graph = None
     if args.graph:
