@@ -176,7 +176,7 @@ def main():
 
     import depth_estimation_amd as de
     wl = WORKLOADS[args.workload]
-    parts = 1 if args.graph else max(1, min(args.streams, wl["B"]))
+    parts = max(1, min(args.streams, wl["B"]))
     scales = build_problem(de, wl, dev, rank, args.image_grad, parts)
     st = torch.cuda.current_stream().cuda_stream
     # one stream per (pyramid level, sub-batch): the levels are independent calls too (BASELINE config 3)
@@ -199,16 +199,23 @@ def main():
 
     graph = None
     if args.graph:
-        side = torch.cuda.Stream()
-        with torch.cuda.stream(side):
-            st_side = side.cuda_stream
-            for sc in scales:
-                sc.step(st_side)
+        # capture one step (all sub-batches, all streams: fork from / join into the capturing stream) and replay it
+        cap = torch.cuda.Stream()
+        with torch.cuda.stream(cap):
+            step()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                for sc in scales:
-                    sc.step(torch.cuda.current_stream().cuda_stream)
+            with torch.cuda.graph(graph, stream=cap):
+                if parts == 1:
+                    for sc in scales:
+                        sc.step(torch.cuda.current_stream().cuda_stream)
+                else:
+                    cur = torch.cuda.current_stream()
+                    for ss in side_streams:
+                        ss.wait_stream(cur)
+                    step()
+                    for ss in side_streams:
+                        cur.wait_stream(ss)
         run = graph.replay
     else:
         run = step
@@ -274,7 +281,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "targets_per_gpu": wl["B"], "sources_per_target": wl["S"],
                        "height": wl["H"], "width": wl["W"], "scales": wl["scales"], "image_grad": bool(args.image_grad),
-                       "launch": "hipgraph" if args.graph else ("eager" if parts == 1 else f"eager, {parts} sub-batches on {parts} streams"),
+                       "launch": ("hipgraph" if args.graph else "eager") + ("" if parts == 1 else f", {parts} sub-batches on {parts} streams"),
                        "parallelism": f"batch-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
