@@ -14,9 +14,6 @@
 // rounded divide: bit-identical to torch's avg_pool2d.  VALU-heavy by necessity:
 // 5 window sums x 9 taps per (pixel, channel, image pair) cannot be shared between windows without
 // changing the rounding order.
-#ifndef DS_DYN_LDS
-#define DS_DYN_LDS 0
-#endif
 #ifndef DS_EXP
 #define DS_EXP 0   // experiments (scripts/build_exp.sh), forward kernel, bit mask: 1 = synthetic row values instead of
                    // global loads, 2 = no cross-wave combine (no barrier), 4 = no LDS neighbour exchange, 8 = no SSIM formula
@@ -24,7 +21,6 @@
 #include "ds_common.h"
 #include "depthsynth.h"
 #include <math.h>
-#include <stdlib.h>
 
 using namespace ds;
 
@@ -868,11 +864,9 @@ inline Geom make_fwd_lds_geom(int B, int H, int W) {
     g.nbx = (W + 63) / 64;
     const long long capacity = simd_count();  // workgroups resident at once: 4 per CU = one per SIMD
     const long long bands = (long long)B * g.nbx;
-    static const int forced = getenv("DS_FWD_NBY") ? atoi(getenv("DS_FWD_NBY")) : 0;  // tuning experiments only
     long long nby = (8 * capacity + bands - 1) / bands;
     const int max_nby = H / 12 > 1 ? H / 12 : 1;
     if (nby > max_nby) nby = max_nby;
-    if (forced > 0) nby = forced < H ? forced : H;
     g.RB = (H + (int)nby - 1) / (int)nby;
     g.nby = (H + g.RB - 1) / g.RB;
     g.nblocks = B * g.nbx * g.nby;
@@ -938,10 +932,10 @@ template <bool FUSED>
 int launch_photo_bwd(int S, const PhotoBwdParams& P, int nblocks, hipStream_t st) {
     dim3 g(nblocks), b(64 * kWaves);
     switch (S) {
-        case 1: hipLaunchKernelGGL((photo_bwd_kernel<1, FUSED>), g, b, DS_DYN_LDS, st, P); break;
-        case 2: hipLaunchKernelGGL((photo_bwd_kernel<2, FUSED>), g, b, DS_DYN_LDS, st, P); break;
-        case 3: hipLaunchKernelGGL((photo_bwd_kernel<3, FUSED>), g, b, DS_DYN_LDS, st, P); break;
-        case 4: hipLaunchKernelGGL((photo_bwd_kernel<4, FUSED>), g, b, DS_DYN_LDS, st, P); break;
+        case 1: hipLaunchKernelGGL((photo_bwd_kernel<1, FUSED>), g, b, 0, st, P); break;
+        case 2: hipLaunchKernelGGL((photo_bwd_kernel<2, FUSED>), g, b, 0, st, P); break;
+        case 3: hipLaunchKernelGGL((photo_bwd_kernel<3, FUSED>), g, b, 0, st, P); break;
+        case 4: hipLaunchKernelGGL((photo_bwd_kernel<4, FUSED>), g, b, 0, st, P); break;
         default: return DS_ERR_UNSUPPORTED;
     }
     DS_CHECK_LAUNCH();
