@@ -4,19 +4,19 @@
 // Reference: metrics.reprojection_error (metrics.py:21-51), metrics.reprojection_loss
 // (metrics.py:54-72), loss assembly train.py:80-92, and their autograd.
 //
-// Kernel shape ("rolling wave"): one 64-lane wavefront owns a band of columns (one column per lane) and
-// walks down a chunk of rows.  Each lane keeps the last three rows of every plane in registers; the
-// left/right neighbours of the 3x3 window come from the adjacent lanes through DPP wave shifts that fold
-// into the adds, so the stencil needs no LDS and every global access is a 256-B coalesced row segment.
-// Halo columns/rows are re-loaded (reflect-indexed, which is exactly functional.pad(mode="reflect")).
+// Kernel shape: a wave owns a band of 64 adjacent columns (one column per lane) of ONE colour channel and walks down a
+// chunk of rows.  Every plane keeps two rolling partial sums per lane (roll()); the left/right neighbours of the 3x3
+// window come from the adjacent lanes through a per-wave LDS row, so the VALU sees only plain adds and every global
+// access is a 256-B coalesced row segment.  Halo columns/rows are re-loaded reflect-indexed, which is exactly
+// functional.pad(mode="reflect").  The forward's three channel waves meet in a fourth wave through an LDS slab
+// (DESIGN.md 4.1); the backward's channel waves are independent.
 //
 // The 9-tap sums are sequential, row-major, separately rounded, then divided by 9 with a correctly
 // rounded divide: bit-identical to torch's avg_pool2d.  VALU-heavy by necessity:
 // 5 window sums x 9 taps per (pixel, channel, image pair) cannot be shared between windows without
 // changing the rounding order.
 #ifndef DS_EXP
-#define DS_EXP 0   // experiments (scripts/build_exp.sh), forward kernel, bit mask: 1 = synthetic row values instead of
-                   // global loads, 2 = no cross-wave combine (no barrier), 4 = no LDS neighbour exchange, 8 = no SSIM formula
+#define DS_EXP 0   // experiment (scripts/build_exp.sh), forward kernel: 1 = synthetic row values instead of global loads
 #endif
 #include "ds_common.h"
 #include "depthsynth.h"

@@ -3,9 +3,11 @@
 // Reference: synthesis.reproject_from_depth (synthesis.py:83-116), synthesis.synthesize
 // (synthesis.py:36-54) and their autograd; callers train.py:72-77.
 //
-// All kernels here are one-thread-per-pixel streaming kernels: planar NCHW images, consecutive lanes
-// on consecutive x, so depth reads / warped writes are 256-B coalesced per wave and the 4x3 corner
-// gathers hit neighbouring source texels (L1/L2-resident lines).  HBM-bound by design; no LDS.
+// All kernels here hold one pixel per lane on planar NCHW images, consecutive lanes on consecutive x, so depth reads /
+// warped writes are 256-B coalesced per wave and the 4x3 corner gathers hit neighbouring source texels (L1/L2-
+// resident lines); no LDS except the pose-gradient block reduction.  The two hot ones (warp_fwd_kernel,
+// warp_bwd_kernel) are tiled and written for instruction count (see the comment above WarpGeom in ds_warp_dev.h's
+// users below); the per-function entry points of the reference's unfused call sequence keep the simple form.
 #include "ds_common.h"
 #include "ds_warp_dev.h"
 #include "depthsynth.h"
