@@ -282,6 +282,30 @@ def test_smoothness(de, oracle):
         assert rel_to_max(N(dep.grad), d["g_depth_reg"]) < 1e-4
 
 
+def test_train_step_loss_matches_per_sample_composition(de):
+    """fused.train_step_loss (train.py:83-89 for B targets at once) == the per-sample composition the reference
+    writes: sum_b [ mean(out/exp(idt+1e-6)) + 0.02 * regularization_term(depth_b/80, target x S) ], values and
+    gradients (1e-4 relative)."""
+    g = torch.Generator().manual_seed(7)
+    B, S, H, W = 3, 2, 40, 72
+    src = torch.rand(B, S, 3, H, W, generator=g).to(DEV)
+    tgt = torch.rand(B, 3, H, W, generator=g).to(DEV)
+    depth = (1 + 79 * torch.rand(B, S, 1, H, W, generator=g)).to(DEV)
+    pose = de.ops.pose_from_vec((0.01 * torch.randn(B * S, 6, generator=g)).to(DEV)).reshape(B, S, 3, 4)
+    K, Kinv = [t.to(DEV) for t in de.fused.intrinsics(W, H)]
+    d1 = depth.clone().requires_grad_(True)
+    r = de.fused.train_step_loss(src, tgt, d1, pose, K, Kinv)
+    r["total"].backward()
+    d2 = depth.clone().requires_grad_(True)
+    total = 0.0
+    for b in range(B):
+        rb = de.fused.fused_reprojection_loss(src[b:b + 1], tgt[b:b + 1], d2[b:b + 1], pose[b:b + 1], K, Kinv)
+        total = total + rb["loss"].sum() + 0.02 * de.metrics.regularization_term(d2[b] / 80.0, torch.stack([tgt[b]] * S))
+    total.backward()
+    assert abs(float(r["total"]) - float(total)) < 1e-5 * abs(float(total))
+    assert rel_to_max(N(d1.grad), N(d2.grad)) < 1e-4
+
+
 def test_ingest_u8_matches_to_tensor(de):
     """to_tensor of the resized frames on the device == the float tensors the reference computed from the
     same uint8 frames (dataset.py:51; fixtures real_*_frames_u8.npz and the src/target of real_*.npz), bit-exact;
