@@ -16,7 +16,8 @@
 // 5 window sums x 9 taps per (pixel, channel, image pair) cannot be shared between windows without
 // changing the rounding order.
 #ifndef DS_EXP
-#define DS_EXP 0   // experiment (scripts/build_exp.sh), forward kernel: 1 = synthetic row values instead of global loads
+#define DS_EXP 0   // experiments (scripts/build_exp.sh), forward kernel, bit mask: 1 = synthetic row values instead of
+                   // global loads, 2 = no workgroup barriers (wrong results; timing only)
 #endif
 #include "ds_common.h"
 #include "depthsynth.h"
@@ -129,7 +130,9 @@ __global__ __launch_bounds__(64 * kFwdWaves, (IDT ? 2 * S : S) > 4 ? 3 : 4) void
         float sum_ratio = 0.f, sum_out = 0.f;
         const int nrows = yend - y0;
         for (int k0 = 0; k0 < nrows; k0 += kK) {
+#if !(DS_EXP & 2)
             __syncthreads();  // the channel waves have filled slab (k0 / kK) & 1
+#endif
             const int buf = (k0 / kK) & 1;
             const int kn = min(kK, nrows - k0);
             for (int k = 0; k < kn; ++k) {
@@ -275,7 +278,9 @@ __global__ __launch_bounds__(64 * kFwdWaves, (IDT ? 2 * S : S) > 4 ? 3 : 4) void
                 ssim_from_sums(ax[g], axx[g], axy[g], ts, so);
                 slab[c][g][lane] = 0.85f * clamp01(so.v) + 0.15f * fabsf(Yp - Xp[g]);
             }
+#if !(DS_EXP & 2)
             if (k % kK == kK - 1 || r == yend) __syncthreads();  // slab full: hand it to the E wave
+#endif
         }
         Yp = yC;
 #pragma unroll
