@@ -35,6 +35,10 @@ _SIGNATURES = {
     "ds_depth_from_costs": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp]),
     "ds_plane_sweep_depth": (_i, [_fp, _fp, _fp, C.POINTER(C.c_double), _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp,
                                   _fp]),
+    "ds_plane_sweep_depth_batch": (_i, [_fp, _fp, _fp, C.POINTER(C.c_double), _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i,
+                                        _i, _fp, _fp]),
+    "ds_resize_bilinear": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp]),
+    "ds_resize_bicubic": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp]),
     "ds_cost_volume": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp]),
     "ds_ssim_fwd": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp]),
     "ds_ssim_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _fp, _fp]),

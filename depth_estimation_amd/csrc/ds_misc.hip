@@ -99,8 +99,9 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_depth_kernel(const float
                                                                      const float* __restrict__ Kinv,
                                                                      const float* __restrict__ pose, Planes planes, int D,
                                                                      const float* __restrict__ src,
-                                                                     const float* __restrict__ target, int Cdyn, WarpGeom G,
-                                                                     int sid, float* __restrict__ depth) {
+                                                                     const float* __restrict__ target, int per_target,
+                                                                     int Cdyn, WarpGeom G, int sid,
+                                                                     float* __restrict__ depth) {
     const int n = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int bx = blockIdx.x % G.nbx, by = blockIdx.x / G.nbx;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_depth_kernel(const float
     Cam cam;
     load_cam(cam, K, Kinv, pose + 12 * n);
     const rsrc_t sp = make_rsrc(src + (size_t)n * Cc * HsWs);
-    const rsrc_t tp = make_rsrc(target);
+    const rsrc_t tp = make_rsrc(target + (size_t)(n / per_target) * Cc * HW);  // uniform: n is blockIdx.y
     const unsigned po = (unsigned)xc * 4u, ro = (unsigned)(y * G.W);
     // the ray of this pixel (synthesis.py:100), shared by all planes
     float ray[3];
@@ -402,6 +403,73 @@ __global__ __launch_bounds__(kThreads) void ingest_u8_kernel(const uint8_t* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// the two resizes around the plane sweep (train.py:55 bilinear, train.py:60 bicubic; align_corners=False, size given,
+// so the scale is in/out in fp32 as ATen's area_pixel_compute_scale forms it).  One thread per output pixel.
+// ---------------------------------------------------------------------------------------------------
+struct ResizeGeom { int Hin, Win, Hout, Wout; float sy, sx; };
+
+__global__ __launch_bounds__(kThreads) void resize_bilinear_kernel(const float* __restrict__ in, ResizeGeom G,
+                                                                   float* __restrict__ out) {
+    const int p = blockIdx.x * kThreads + threadIdx.x;
+    if (p >= G.Hout * G.Wout) return;
+    const int oy = p / G.Wout, ox = p - oy * G.Wout;
+    // source index scale*(dst+0.5)-0.5, negative values clamp to 0; upper neighbour clamps to the last row/column
+    const float ry = fmaxf(fmaf(G.sy, (float)oy + 0.5f, -0.5f), 0.f), rx = fmaxf(fmaf(G.sx, (float)ox + 0.5f, -0.5f), 0.f);
+    const int y0 = min((int)ry, G.Hin - 1), x0 = min((int)rx, G.Win - 1);
+    const int y1 = min(y0 + 1, G.Hin - 1), x1 = min(x0 + 1, G.Win - 1);
+    const float ly = fminf(fmaxf(ry - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(rx - (float)x0, 0.f), 1.f);
+    const float* pl = in + (size_t)blockIdx.y * G.Hin * G.Win;
+    const float top = fmaf(1.f - lx, pl[y0 * G.Win + x0], lx * pl[y0 * G.Win + x1]);
+    const float bot = fmaf(1.f - lx, pl[y1 * G.Win + x0], lx * pl[y1 * G.Win + x1]);
+    out[(size_t)blockIdx.y * G.Hout * G.Wout + p] = fmaf(1.f - ly, top, ly * bot);
+}
+
+// Keys cubic convolution, A = -0.75 (ATen get_cubic_upsample_coefficients)
+__device__ __forceinline__ void cubic_coefs(float t, float c[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x3 = 2.f - t, x2 = 1.f - t;
+    c[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    c[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    c[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    c[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+__global__ __launch_bounds__(kThreads) void resize_bicubic_kernel(const float* __restrict__ in, ResizeGeom G,
+                                                                  float* __restrict__ out) {
+    const int p = blockIdx.x * kThreads + threadIdx.x;
+    if (p >= G.Hout * G.Wout) return;
+    const int oy = p / G.Wout, ox = p - oy * G.Wout;
+    const float ry = fmaf(G.sy, (float)oy + 0.5f, -0.5f), rx = fmaf(G.sx, (float)ox + 0.5f, -0.5f);   // not clamped for cubic
+    const float fy = floorf(ry), fx = floorf(rx);
+    const int iy = (int)fy, ix = (int)fx;
+    float cy[4], cx[4];
+    cubic_coefs(fminf(fmaxf(ry - fy, 0.f), 1.f), cy);
+    cubic_coefs(fminf(fmaxf(rx - fx, 0.f), 1.f), cx);
+    int xs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xs[i] = min(max(ix - 1 + i, 0), G.Win - 1);
+    const float* pl = in + (size_t)blockIdx.y * G.Hin * G.Win;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float* row = pl + (size_t)min(max(iy - 1 + j, 0), G.Hin - 1) * G.Win;
+        float r = cx[0] * row[xs[0]];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) r += cx[i] * row[xs[i]];
+        acc = (j == 0) ? cy[0] * r : acc + cy[j] * r;
+    }
+    out[(size_t)blockIdx.y * G.Hout * G.Wout + p] = acc;
+}
+
+inline bool resize_geom(ResizeGeom& G, int N, int Hin, int Win, int Hout, int Wout) {
+    if (N <= 0 || N > 65535 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || (long long)Hin * Win > (1ll << 30) ||
+        (long long)Hout * Wout > (1ll << 30))
+        return false;
+    G = ResizeGeom{Hin, Win, Hout, Wout, (float)Hin / (float)Hout, (float)Win / (float)Wout};
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -445,23 +513,35 @@ int ds_depth_from_costs(const float* cost, int N, int D, int H, int W, int sid, 
     return DS_OK;
 }
 
+static int plane_sweep_launch(const float* K, const float* Kinv, const float* pose, const double* depths_host, int D,
+                              const float* src, const float* targets, int B, int S, int C, int Hs, int Ws, int H, int W,
+                              int sid, float* depth, void* stream) {
+    Planes pl;
+    if (!K || !Kinv || !pose || !src || !targets || !depth || B <= 0 || S <= 0 || (long long)B * S > 65535 ||
+        bad_img(B * S, C, H, W) || Hs < 2 || Ws < 2 || !fill_planes(pl, depths_host, D))
+        return DS_ERR_INVALID_ARG;
+    const WarpGeom G = warp_geom(Hs, Ws, H, W);
+    dim3 grid(G.nbx * ((H + kThreads / 64 - 1) / (kThreads / 64)), B * S), blk(kThreads);
+    if (C == 3)
+        hipLaunchKernelGGL(plane_sweep_depth_kernel<3>, grid, blk, 0, (hipStream_t)stream, K, Kinv, pose, pl, D, src,
+                           targets, S, C, G, sid, depth);
+    else
+        hipLaunchKernelGGL(plane_sweep_depth_kernel<0>, grid, blk, 0, (hipStream_t)stream, K, Kinv, pose, pl, D, src,
+                           targets, S, C, G, sid, depth);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
 int ds_plane_sweep_depth(const float* K, const float* Kinv, const float* pose, const double* depths_host, int D,
                          const float* src, const float* target_small, int NS, int C, int Hs, int Ws, int H, int W,
                          int sid, float* depth, void* stream) {
-    Planes pl;
-    if (!K || !Kinv || !pose || !src || !target_small || !depth || bad_img(NS, C, H, W) || Hs < 2 || Ws < 2 ||
-        !fill_planes(pl, depths_host, D))
-        return DS_ERR_INVALID_ARG;
-    const WarpGeom G = warp_geom(Hs, Ws, H, W);
-    dim3 grid(G.nbx * ((H + kThreads / 64 - 1) / (kThreads / 64)), NS), blk(kThreads);
-    if (C == 3)
-        hipLaunchKernelGGL(plane_sweep_depth_kernel<3>, grid, blk, 0, (hipStream_t)stream, K, Kinv, pose, pl, D, src,
-                           target_small, C, G, sid, depth);
-    else
-        hipLaunchKernelGGL(plane_sweep_depth_kernel<0>, grid, blk, 0, (hipStream_t)stream, K, Kinv, pose, pl, D, src,
-                           target_small, C, G, sid, depth);
-    DS_CHECK_LAUNCH();
-    return DS_OK;
+    return plane_sweep_launch(K, Kinv, pose, depths_host, D, src, target_small, 1, NS, C, Hs, Ws, H, W, sid, depth, stream);
+}
+
+int ds_plane_sweep_depth_batch(const float* K, const float* Kinv, const float* pose, const double* depths_host, int D,
+                               const float* src, const float* targets_small, int B, int S, int C, int Hs, int Ws, int H,
+                               int W, int sid, float* depth, void* stream) {
+    return plane_sweep_launch(K, Kinv, pose, depths_host, D, src, targets_small, B, S, C, Hs, Ws, H, W, sid, depth, stream);
 }
 
 size_t ds_smooth_workspace_bytes(int N, int H, int W) {
@@ -516,6 +596,24 @@ int ds_ingest_u8(const uint8_t* frames, int N, int H, int W, float* out, void* s
     const int HW = H * W, groups = (HW + 3) / 4;
     hipLaunchKernelGGL(ingest_u8_kernel, dim3((groups + kThreads - 1) / kThreads, N), dim3(kThreads), 0, (hipStream_t)stream,
                        frames, HW, out);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_resize_bilinear(const float* in, int N, int Hin, int Win, int Hout, int Wout, float* out, void* stream) {
+    ResizeGeom G;
+    if (!in || !out || !resize_geom(G, N, Hin, Win, Hout, Wout)) return DS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(pix_blocks(Hout * Wout), N), dim3(kThreads), 0, (hipStream_t)stream, in, G,
+                       out);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_resize_bicubic(const float* in, int N, int Hin, int Win, int Hout, int Wout, float* out, void* stream) {
+    ResizeGeom G;
+    if (!in || !out || !resize_geom(G, N, Hin, Win, Hout, Wout)) return DS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(resize_bicubic_kernel, dim3(pix_blocks(Hout * Wout), N), dim3(kThreads), 0, (hipStream_t)stream, in, G,
+                       out);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

@@ -49,3 +49,15 @@ def train_step_loss(src, target, depth, pose, K, Kinv, max_depth: float = 80.0, 
     loss = loss + (smooth_weight * b) * ops.smoothness((depth / max_depth).reshape(b * s, 1, h, w), tg)
     r["total"] = loss
     return r
+
+
+def candidate_depths(src, target, pose, K_cost, Kinv_cost, depths, cost_size, sid: bool = True) -> torch.Tensor:
+    """train.py:49-60 for a whole batch in three launches: the target at cost-volume resolution (bilinear, :55), the
+    plane sweep with its soft arg-min (:49-59), the candidate depth back at image resolution (bicubic, :60).
+    src (B,S,3,H,W), target (B,3,H,W), pose (B,S,3,4), K_cost/Kinv_cost the intrinsics of the cost grid
+    (constants.py:33-37), cost_size (COST_HEIGHT, COST_WIDTH) -> (B,S,1,H,W).  No gradient flows (the reference
+    detaches the plane images, and the arg-min input is built from them)."""
+    h, w = src.shape[-2:]
+    small = ops.resize_bilinear(target, cost_size)
+    cand = ops.plane_sweep_depth_batch(K_cost, Kinv_cost, pose, depths, src, small, sid=sid)
+    return ops.resize_bicubic(cand, (h, w))

@@ -412,3 +412,48 @@ def plane_sweep_depth(K, Kinv, pose, depths, src, target_small, sid: bool = True
                                          target_small.data_ptr(), ns, c, hs, ws, h, w, int(bool(sid)), out.data_ptr(),
                                          L.stream()), "ds_plane_sweep_depth")
     return out
+
+
+def plane_sweep_depth_batch(K, Kinv, pose, depths, src, targets_small, sid: bool = True) -> torch.Tensor:
+    """The loop over the batch of train.py:46-63 in one launch: pose (B,S,3,4), src (B,S,C,Hs,Ws), targets_small
+    (B,C,H,W) -> candidate depth (B,S,1,H,W); row (b, s) equals plane_sweep_depth(..., src[b], targets_small[b])[s]."""
+    src, targets_small = L.dev_f32(src.detach(), "src"), L.dev_f32(targets_small.detach(), "targets_small")
+    if src.dim() != 5 or targets_small.dim() != 4 or src.shape[0] != targets_small.shape[0]:
+        raise ValueError("src must be (B,S,C,Hs,Ws) and targets_small (B,C,H,W) with the same B")
+    b, s_, c, hs, ws = src.shape
+    if targets_small.shape[1] != c:
+        raise ValueError("src and targets_small differ in channels")
+    _, _, h, w = targets_small.shape
+    K, Kinv, pose = _chk_cam(K.detach(), Kinv.detach(), pose.detach().reshape(b * s_, 3, 4), b * s_)
+    L.same_device(src, targets_small, K, Kinv, pose)
+    d, dp = _depths_arg(depths)
+    out = torch.empty(b, s_, 1, h, w, dtype=torch.float32, device=src.device)
+    L.check(L.lib().ds_plane_sweep_depth_batch(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), dp, len(d),
+                                               src.data_ptr(), targets_small.data_ptr(), b, s_, c, hs, ws, h, w,
+                                               int(bool(sid)), out.data_ptr(), L.stream()), "ds_plane_sweep_depth_batch")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# functional.interpolate as train.py:55 / :60 call it
+# ----------------------------------------------------------------------------------------------------
+def _resize(name: str, x: torch.Tensor, size) -> torch.Tensor:
+    x = L.dev_f32(x.detach(), "x")
+    if x.dim() < 2:
+        raise ValueError("x must be (...,H,W)")
+    ho, wo = int(size[0]), int(size[1])
+    hi, wi = x.shape[-2:]
+    n = x.numel() // (hi * wi) if hi * wi else 0
+    out = torch.empty(*x.shape[:-2], ho, wo, dtype=torch.float32, device=x.device)
+    L.check(getattr(L.lib(), name)(x.data_ptr(), n, hi, wi, ho, wo, out.data_ptr(), L.stream()), name)
+    return out
+
+
+def resize_bilinear(x: torch.Tensor, size) -> torch.Tensor:
+    """functional.interpolate(x, size=size, mode="bilinear") (train.py:55); x (...,H,W), no gradient."""
+    return _resize("ds_resize_bilinear", x, size)
+
+
+def resize_bicubic(x: torch.Tensor, size) -> torch.Tensor:
+    """functional.interpolate(x, size=size, mode="bicubic") (train.py:60); x (...,H,W), no gradient."""
+    return _resize("ds_resize_bicubic", x, size)

@@ -93,6 +93,18 @@ int ds_plane_sweep_depth(const float* K, const float* Kinv, const float* pose, c
                          const float* src, const float* target_small, int NS, int C, int Hs, int Ws, int H, int W,
                          int sid, float* depth, void* stream);
 
+/* The same for a batch, one launch: the loop over the batch in train.py:46-63.  pose (B*S,3,4), src (B*S,C,Hs,Ws)
+ * with the S sources of target b at rows b*S..b*S+S-1, targets_small (B,C,H,W) -> depth (B*S,1,H,W).  B*S <= 65535. */
+int ds_plane_sweep_depth_batch(const float* K, const float* Kinv, const float* pose, const double* depths_host, int D,
+                               const float* src, const float* targets_small, int B, int S, int C, int Hs, int Ws, int H,
+                               int W, int sid, float* depth, void* stream);
+
+/* functional.interpolate(x, size=(Hout,Wout), mode="bilinear") of train.py:55 (target -> cost-volume resolution) and
+ * mode="bicubic" of train.py:60 (candidate depth -> image resolution); align_corners=False, no antialias.
+ * in (N,Hin,Win) planes -> out (N,Hout,Wout). */
+int ds_resize_bilinear(const float* in, int N, int Hin, int Win, int Hout, int Wout, float* out, void* stream);
+int ds_resize_bicubic(const float* in, int N, int Hin, int Win, int Hout, int Wout, float* out, void* stream);
+
 /* ---- metrics.py -------------------------------------------------------------------------------- */
 
 /* metrics.cost_volumes (metrics.py:5-18): target (C,H,W), synth (D,C,H,W) -> cost (D,H,W). */

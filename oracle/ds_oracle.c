@@ -656,3 +656,64 @@ DSO_API void dso_depth_from_costs(const float* cost, int N, int D, size_t HW, in
             depth[(size_t)n * HW + p] = sid ? (expf((m + 1.0f) * ln2 / (float)D) - 1.0f) : (m / (float)D + 1.0f / (float)D);
         }
 }
+
+/* ---- the two resizes around the plane sweep ---------------------------------------------------------------
+ * functional.interpolate(x, size=(Hout,Wout), mode="bilinear") of train.py:55 and mode="bicubic" of train.py:60:
+ * align_corners=False, size given (so the scale is in/out in fp32), no antialias.  Source index
+ * fma(scale, dst+0.5, -0.5) (torch's compiled kernels contract it; the golden vectors show it: separate rounding
+ * moves the weights by an ulp of the index, 2e-6 in the result); bilinear clamps it at 0 and the upper neighbour at the last row/column; bicubic floors it,
+ * clamps the four tap indices, and weights them with the Keys kernel, A = -0.75. */
+DSO_API void dso_resize_bilinear(const float* in, int N, int Hin, int Win, int Hout, int Wout, float* out) {
+    const float sy = (float)Hin / (float)Hout, sx = (float)Win / (float)Wout;
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int oy = 0; oy < Hout; ++oy) {
+            const float ry = fmaxf(fmaf(sy, (float)oy + 0.5f, -0.5f), 0.f);
+            const int y0 = (int)ry < Hin - 1 ? (int)ry : Hin - 1, y1 = y0 + 1 < Hin - 1 ? y0 + 1 : Hin - 1;
+            const float ly = fminf(fmaxf(ry - (float)y0, 0.f), 1.f);
+            for (int ox = 0; ox < Wout; ++ox) {
+                const float rx = fmaxf(fmaf(sx, (float)ox + 0.5f, -0.5f), 0.f);
+                const int x0 = (int)rx < Win - 1 ? (int)rx : Win - 1, x1 = x0 + 1 < Win - 1 ? x0 + 1 : Win - 1;
+                const float lx = fminf(fmaxf(rx - (float)x0, 0.f), 1.f);
+                const float* p = in + (size_t)n * Hin * Win;
+                const float top = fmaf(1.f - lx, p[y0 * Win + x0], lx * p[y0 * Win + x1]);
+                const float bot = fmaf(1.f - lx, p[y1 * Win + x0], lx * p[y1 * Win + x1]);
+                out[((size_t)n * Hout + oy) * Wout + ox] = fmaf(1.f - ly, top, ly * bot);
+            }
+        }
+}
+
+static inline void cubic_coefs(float t, float c[4]) {
+    const float A = -0.75f, x0 = t + 1.f, x2 = 1.f - t, x3 = 2.f - t;
+    c[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    c[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    c[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    c[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+DSO_API void dso_resize_bicubic(const float* in, int N, int Hin, int Win, int Hout, int Wout, float* out) {
+    const float sy = (float)Hin / (float)Hout, sx = (float)Win / (float)Wout;
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int oy = 0; oy < Hout; ++oy) {
+            const float ry = fmaf(sy, (float)oy + 0.5f, -0.5f), fy = floorf(ry);
+            float cy[4];
+            cubic_coefs(fminf(fmaxf(ry - fy, 0.f), 1.f), cy);
+            for (int ox = 0; ox < Wout; ++ox) {
+                const float rx = fmaf(sx, (float)ox + 0.5f, -0.5f), fx = floorf(rx);
+                float cx[4];
+                cubic_coefs(fminf(fmaxf(rx - fx, 0.f), 1.f), cx);
+                const float* p = in + (size_t)n * Hin * Win;
+                float acc = 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const float* row = p + (size_t)clampi((int)fy - 1 + j, 0, Hin - 1) * Win;
+                    float r = 0.f;
+                    for (int i = 0; i < 4; ++i) r += cx[i] * row[clampi((int)fx - 1 + i, 0, Win - 1)];
+                    acc += cy[j] * r;
+                }
+                out[((size_t)n * Hout + oy) * Wout + ox] = acc;
+            }
+        }
+}

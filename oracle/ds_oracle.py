@@ -214,3 +214,21 @@ def depth_from_costs(cost, sid: bool = True) -> np.ndarray:
     out = np.empty((N, 1, H, W), np.float32)
     lib().dso_depth_from_costs(_p(cost), N, D, H * W, int(sid), _p(out))
     return out
+
+
+def _resize(fn, x, size) -> np.ndarray:
+    x = _f(x)
+    Hin, Win = x.shape[-2:]
+    out = np.empty(x.shape[:-2] + tuple(size), np.float32)
+    fn(_p(x), int(np.prod(x.shape[:-2], dtype=np.int64)), Hin, Win, size[0], size[1], _p(out))
+    return out
+
+
+def resize_bilinear(x, size) -> np.ndarray:
+    """functional.interpolate(x, size=size, mode="bilinear") of train.py:55; x (...,Hin,Win)."""
+    return _resize(lib().dso_resize_bilinear, x, size)
+
+
+def resize_bicubic(x, size) -> np.ndarray:
+    """functional.interpolate(x, size=size, mode="bicubic") of train.py:60; x (...,Hin,Win)."""
+    return _resize(lib().dso_resize_bicubic, x, size)

@@ -24,3 +24,27 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / n
 px = NS * 80 * 96 * 320
 print(f"plane sweep NS={NS}: {ms*1e3:.1f} us per call, {px/ms/1e6:.2f} Gpix/s (plane-warped pixels), checksum {float(out.sum()):.6f}")
+
+# the batch form (train.py:46-63 as one launch) with its two resizes: B targets x S sources
+B, S = 12, 2
+srcb = torch.rand(B, S, 3, 192, 640, generator=g).to(dev)
+tgtb = torch.rand(B, 3, 192, 640, generator=g).to(dev)
+poseb = ops.pose_from_vec((0.01 * torch.randn(B * S, 6, generator=g)).to(dev)).reshape(B, S, 3, 4).contiguous()
+for _ in range(5):
+    full = de.fused.candidate_depths(srcb, tgtb, poseb, K, Kinv, depths, (96, 320))
+torch.cuda.synchronize()
+e0.record()
+for _ in range(n):
+    full = de.fused.candidate_depths(srcb, tgtb, poseb, K, Kinv, depths, (96, 320))
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / n
+print(f"candidate_depths B={B} S={S} (bilinear + sweep + bicubic): {ms*1e3:.1f} us per call, "
+      f"{B*S*80*96*320/ms/1e6:.2f} Gpix/s, checksum {float(full.sum()):.6f}")
+t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+t0.record()
+for _ in range(n):
+    ref_small = torch.nn.functional.interpolate(tgtb, size=(96, 320), mode="bilinear")
+    ref_full = torch.nn.functional.interpolate(full[:, 0], size=(192, 640), mode="bicubic")
+t1.record(); torch.cuda.synchronize()
+print(f"torch's two interpolate calls alone: {t0.elapsed_time(t1)/n*1e3:.1f} us; "
+      f"max|bilinear diff| {float((ref_small - ops.resize_bilinear(tgtb, (96, 320))).abs().max()):.2e}")

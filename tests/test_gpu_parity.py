@@ -257,6 +257,46 @@ def test_plane_sweep(de, oracle):
         assert np.abs(N(fused) - d[key]).max() < 1e-5
 
 
+def test_resizes(de, oracle):
+    """train.py:55 / :60: against the torch-made vectors (1e-5, north_star) and the oracle (same operation order: 1e-6)."""
+    d = load_golden("resize_vectors")
+    ps = load_golden("plane_sweep_24x80")
+    assert np.abs(N(de.ops.resize_bilinear(T(ps["target"]), (24, 80))) - ps["target_small"][0]).max() < 1e-5
+    assert np.abs(N(de.ops.resize_bicubic(T(ps["cand_sid"]), (48, 160))) - d["cand_full"]).max() < 1e-5
+    for key, tag, size in (("a", "a_19x20", (19, 20)), ("a", "a_50x131", (50, 131)), ("a", "a_1x1", (1, 1)),
+                           ("b", "b_37x53", (37, 53)), ("b", "b_7x64", (7, 64))):
+        for mode in ("bilinear", "bicubic"):
+            got = N(getattr(de.ops, "resize_" + mode)(T(d[key]), size))
+            assert got.shape == d[mode + "_" + tag].shape
+            assert np.abs(got - d[mode + "_" + tag]).max() < 1e-5, (mode, tag)
+            assert np.abs(got - getattr(oracle, "resize_" + mode)(d[key], size)).max() < 1e-6, (mode, tag)
+    with pytest.raises(RuntimeError):
+        de.ops.resize_bilinear(T(d["a"]), (0, 4))
+
+
+def test_candidate_depths_batch(de, oracle):
+    """train.py:49-60 for a batch in three launches == the per-target calls; golden: plane_sweep_24x80 + resize_vectors."""
+    d = load_golden("plane_sweep_24x80")
+    r = load_golden("resize_vectors")
+    K, Kinv = T(d["K"]), T(d["Kinv"])
+    # batch of 3 targets: the fixture's sequence, the same with sources swapped, and a synthetic one
+    rng = np.random.default_rng(5)
+    src = np.stack([d["src"], d["src"][::-1], rng.random(d["src"].shape, dtype=np.float32)])
+    tgt = np.stack([d["target"], d["target"], rng.random(d["target"].shape, dtype=np.float32)])
+    pose = np.stack([d["pose_mats"], d["pose_mats"][::-1], d["pose_mats"]])
+    small = de.ops.resize_bilinear(T(tgt), (24, 80))
+    got = de.ops.plane_sweep_depth_batch(K, Kinv, T(pose), d["depths"], T(src), small)
+    assert got.shape == (3, 2, 1, 24, 80)
+    for b in range(3):
+        one = de.ops.plane_sweep_depth(K, Kinv, T(pose[b]), d["depths"], T(src[b]), small[b])
+        assert np.array_equal(N(got[b]), N(one)), b
+    assert np.abs(N(got[0]) - d["cand_sid"]).max() < 1e-5
+    full = de.fused.candidate_depths(T(src), T(tgt), T(pose), K, Kinv, d["depths"], (24, 80))
+    assert full.shape == (3, 2, 1, 48, 160)
+    assert np.abs(N(full[0]) - r["cand_full"]).max() < 2e-5
+    assert np.abs(N(full[1])[::-1] - r["cand_full"]).max() < 2e-5
+
+
 def test_depth_metrics(de, oracle):
     d = load_golden("metrics_3x40x96")
     pred, gt = T(d["pred"]), T(d["gt"])

@@ -127,6 +127,23 @@ def test_plane_sweep_cost_volume_softargmin(oracle):
     assert np.abs(oracle.depth_from_costs(cv, False) - d["cand_uid"]).max() < 1e-5
 
 
+RESIZE_CASES = (("a", "a_19x20", (19, 20)), ("a", "a_50x131", (50, 131)), ("a", "a_1x1", (1, 1)),
+                ("b", "b_37x53", (37, 53)), ("b", "b_7x64", (7, 64)))
+
+
+def test_resizes(oracle):
+    """functional.interpolate as train.py:55 (bilinear) and :60 (bicubic) call it.  The vectors are torch CPU's; its
+    vectorised sums associate differently from the scalar restatement: 2.5e-7 bilinear (one ulp), 2e-6 bicubic (16
+    signed terms); north_star asks for 1e-5."""
+    d = load_golden("resize_vectors")
+    ps = load_golden("plane_sweep_24x80")
+    assert np.abs(oracle.resize_bilinear(ps["target"], (24, 80)) - ps["target_small"][0]).max() < 2.5e-7
+    assert np.abs(oracle.resize_bicubic(ps["cand_sid"], (48, 160)) - d["cand_full"]).max() < 2e-6
+    for key, tag, size in RESIZE_CASES:
+        assert np.abs(oracle.resize_bilinear(d[key], size) - d["bilinear_" + tag]).max() < 2.5e-7, tag
+        assert np.abs(oracle.resize_bicubic(d[key], size) - d["bicubic_" + tag]).max() < 2e-6, tag
+
+
 def test_depth_metrics(oracle):
     d = load_golden("metrics_3x40x96")
     m = oracle.depth_metrics(d["pred"], d["gt"])

@@ -278,8 +278,28 @@ def case_pose(name):
     print(name, "ok")
 
 
+def case_resize(name):
+    """the two functional.interpolate calls of train.py:55 and :60, at the plane-sweep fixture's sizes and at ragged ones."""
+    ps = np.load(os.path.join(OUT, "plane_sweep_24x80.npz"))
+    cand = torch.from_numpy(ps["cand_sid"])                       # (2,1,24,80), train.py:59
+    cand_full = torch.nn.functional.interpolate(cand, size=(48, 160), mode="bicubic")      # train.py:60
+    gen = torch.Generator().manual_seed(123)
+    a = torch.rand(2, 3, 37, 53, generator=gen)
+    b = torch.rand(3, 1, 19, 20, generator=gen)
+    rec = dict(cand_full=npf(cand_full), a=npf(a), b=npf(b))
+    for tag, x, size in (("a_19x20", a, (19, 20)), ("a_50x131", a, (50, 131)), ("a_1x1", a, (1, 1)),
+                         ("b_37x53", b, (37, 53)), ("b_7x64", b, (7, 64))):
+        rec["bilinear_" + tag] = npf(torch.nn.functional.interpolate(x, size=size, mode="bilinear"))
+        rec["bicubic_" + tag] = npf(torch.nn.functional.interpolate(x, size=size, mode="bicubic"))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(name, "ok")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["resize"]:                                # added later; leaves the other fixtures untouched
+        case_resize("resize_vectors")
+        return
     case_real("real_48x160", 160, 48, full=True, sub=1)
     case_real("real_192x640", 640, 192, full=False, sub=8)       # BASELINE config 1
     case_synth("synth_24x80", S=2, H=24, W=80, seed=0, pose_scale=0.01)
@@ -291,6 +311,7 @@ def main():
     case_plane_sweep("plane_sweep_24x80")
     case_metrics("metrics_3x40x96")
     case_pose("pose_batch")
+    case_resize("resize_vectors")
 
 
 if __name__ == "__main__":
