@@ -28,9 +28,10 @@ WORKLOADS = {
     # BASELINE.json metric: "fwd+bwd reproj loss @192x640" on the config-2/3 batch
     "b12_s2_192x640_fwdbwd": dict(B=12, S=2, H=192, W=640, scales=1),
     # config 3: the same over a 4-scale pyramid (each scale an independent call, K rows scaled per scale)
-    "b12_s2_192x640_pyramid4_fwdbwd": dict(B=12, S=2, H=192, W=640, scales=4),
-    # config 4: the HBM-resident-set-exceeds-cache case
-    "b64_s2_320x1024_fwdbwd": dict(B=64, S=2, H=320, W=1024, scales=1),
+    # (the backward also scatters the source-image gradient)
+    "b12_s2_192x640_pyramid4_fwdbwd": dict(B=12, S=2, H=192, W=640, scales=4, image_grad=True),
+    # config 4: the HBM-resident-set-exceeds-cache case; the step ends with the depth-metrics reduction on (B,1,H,W)
+    "b64_s2_320x1024_fwdbwd": dict(B=64, S=2, H=320, W=1024, scales=1, metrics=True),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
@@ -38,7 +39,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 class Scale:
     """All device buffers of one (B,S,H,W) problem + the four C-ABI calls of a step."""
 
-    def __init__(self, de, B, S, H, W, dev, seed, image_grad):
+    def __init__(self, de, B, S, H, W, dev, seed, image_grad, metrics=False):
         from depth_estimation_amd import _lib as L
         self.L, self.lib = L, L.lib()
         self.B, self.S, self.H, self.W, self.N = B, S, H, W, B * S
@@ -67,6 +68,15 @@ class Scale:
         self.ws_warp = torch.empty(self.ws_warp_n, dtype=torch.uint8, device=dev)
         p = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
         lib, N = self.lib, self.N
+        self.names = ("warp_fwd", "loss_fwd", "loss_bwd", "warp_bwd") + (("metrics",) if metrics else ())
+        if metrics:
+            # test.py:73-81 on the first source's depth map; ground truth U(1,80) with 30 % invalid (zero) pixels
+            self.gt = (1 + 79 * torch.rand(B, 1, H, W, generator=g)).to(dev)
+            self.gt[torch.rand(B, 1, H, W, generator=g).to(dev) < 0.3] = 0.0
+            self.pred = self.depth[:, 0].contiguous()
+            self.met = torch.empty(8, **f)
+            self.ws_met_n = self.lib.ds_metrics_workspace_bytes(B, H, W)
+            self.ws_met = torch.empty(self.ws_met_n, dtype=torch.uint8, device=dev)
         self.calls = {
             "warp_fwd": lambda st: lib.ds_warp_fwd(p(self.K), p(self.Kinv), p(self.pose), p(self.depth), p(self.src), N, 3,
                                                     H, W, H, W, p(self.warped), st),
@@ -79,6 +89,9 @@ class Scale:
                                                    p(self.g_warped), N, 3, H, W, H, W, p(self.g_depth), p(self.g_pose),
                                                    p(self.g_src), p(self.ws_warp), self.ws_warp_n, st),
         }
+        if metrics:
+            self.calls["metrics"] = lambda st: lib.ds_depth_metrics(p(self.pred), p(self.gt), B, H, W, p(self.met),
+                                                                    p(self.ws_met), self.ws_met_n, st)
         # algorithmic HBM bytes of each call: every input read once, every output written once
         px, tp = self.N * H * W, B * H * W
         self.alg_bytes = {
@@ -87,11 +100,13 @@ class Scale:
             "loss_bwd": px * (12 + 12) + tp * (12 + 4 + 1),       # warped + target + idt + aux -> g_warped
             "warp_bwd": px * (4 + 12 + 12 + 4 + (12 if image_grad else 0)),  # depth + src + g_warped -> g_depth [+ g_src]
         }
+        if metrics:
+            self.alg_bytes["metrics"] = tp * 8                    # pred + gt
 
     def step(self, st):
         if self.g_src is not None:
             self.g_src.zero_()
-        for name in ("warp_fwd", "loss_fwd", "loss_bwd", "warp_bwd"):
+        for name in self.names:
             rc = self.calls[name](st)
             if rc != 0:
                 self.L.check(rc, name)
@@ -107,7 +122,8 @@ def build_problem(de, wl, dev, rank, image_grad, parts=1):
         for j in range(lvl_parts):
             b = wl["B"] // lvl_parts + (1 if j < wl["B"] % lvl_parts else 0)
             if b > 0:
-                scales.append(Scale(de, b, wl["S"], wl["H"] >> i, wl["W"] >> i, dev, 1000 * rank + 10 * i + j, image_grad))
+                scales.append(Scale(de, b, wl["S"], wl["H"] >> i, wl["W"] >> i, dev, 1000 * rank + 10 * i + j, image_grad,
+                                    wl.get("metrics", False)))
     return scales
 
 
@@ -178,7 +194,8 @@ def main():
     import depth_estimation_amd as de
     wl = WORKLOADS[args.workload]
     parts = max(1, min(args.streams, wl["B"]))
-    scales = build_problem(de, wl, dev, rank, args.image_grad, parts)
+    image_grad = args.image_grad or wl.get("image_grad", False)
+    scales = build_problem(de, wl, dev, rank, image_grad, parts)
     st = torch.cuda.current_stream().cuda_stream
     # one stream per (pyramid level, sub-batch): the levels are independent calls too (BASELINE config 3)
     side_streams = [torch.cuda.Stream() for _ in range(len(scales))] if parts > 1 else []
@@ -192,7 +209,7 @@ def main():
         for sc in scales:
             if sc.g_src is not None:
                 sc.g_src.zero_()
-        for name in ("warp_fwd", "loss_fwd", "loss_bwd", "warp_bwd"):
+        for name in scales[0].names:
             for j, sc in enumerate(scales):
                 rc = sc.calls[name](side_streams[j].cuda_stream)
                 if rc != 0:
@@ -264,11 +281,11 @@ def main():
 
     # per-kernel durations: HIP events on the launch stream around each call, inside the same step sequence
     # (whole batch of the finest level on the current stream, whatever --streams says: kernels do not overlap here)
-    names = ("warp_fwd", "loss_fwd", "loss_bwd", "warp_bwd")
+    names = scales[0].names
     step_bytes = sum(sum(sc.alg_bytes.values()) for sc in scales)
     if parts > 1:
         del scales
-        scales = build_problem(de, wl, dev, rank, args.image_grad, 1)
+        scales = build_problem(de, wl, dev, rank, image_grad, 1)
     sc0 = scales[0]
     ev = {n: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
           for n in names}
@@ -301,7 +318,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "targets_per_gpu": wl["B"], "sources_per_target": wl["S"],
-                       "height": wl["H"], "width": wl["W"], "scales": wl["scales"], "image_grad": bool(args.image_grad),
+                       "height": wl["H"], "width": wl["W"], "scales": wl["scales"], "image_grad": bool(image_grad),
+                       "metrics_reduce": bool(wl.get("metrics", False)),
                        "launch": ("hipgraph" if args.graph else "eager") + ("" if parts == 1 else f", {parts} sub-batches on {parts} streams"),
                        "parallelism": f"batch-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -37,6 +37,7 @@ _SIGNATURES = {
                                   _fp]),
     "ds_plane_sweep_depth_batch": (_i, [_fp, _fp, _fp, C.POINTER(C.c_double), _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i,
                                         _i, _fp, _fp]),
+    "ds_ingest_depth_u16": (_i, [_fp, _i, _i, _i, _fp, _fp]),
     "ds_resize_bilinear": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp]),
     "ds_resize_bicubic": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp]),
     "ds_cost_volume": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp]),

@@ -374,6 +374,21 @@ inline bool fill_planes(Planes& pl, const double* depths_host, int D) {
 // (dataset.py:51,110): uint8 HWC -> float32 CHW, value / 255 (true divide).  Four pixels per thread: 12 interleaved
 // bytes in, one float4 per channel out.
 // ---------------------------------------------------------------------------------------------------
+// ground-truth depth (dataset.py:116-120): 16-bit PNG samples -> float32, divided by 2**16 (exact: a power of two)
+__global__ __launch_bounds__(kThreads) void ingest_depth_u16_kernel(const uint16_t* __restrict__ in, size_t n,
+                                                                    float* __restrict__ out) {
+    const size_t i = ((size_t)blockIdx.x * kThreads + threadIdx.x) * 2;
+    if (i + 1 < n) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(in + i);
+        float2 f;
+        f.x = (float)(w & 0xffffu) * (1.0f / 65536.0f);
+        f.y = (float)(w >> 16) * (1.0f / 65536.0f);
+        *reinterpret_cast<float2*>(out + i) = f;
+    } else if (i < n) {
+        out[i] = (float)in[i] * (1.0f / 65536.0f);
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void ingest_u8_kernel(const uint8_t* __restrict__ frames, int HW,
                                                              float* __restrict__ out) {
     const int n = blockIdx.y;
@@ -596,6 +611,16 @@ int ds_ingest_u8(const uint8_t* frames, int N, int H, int W, float* out, void* s
     const int HW = H * W, groups = (HW + 3) / 4;
     hipLaunchKernelGGL(ingest_u8_kernel, dim3((groups + kThreads - 1) / kThreads, N), dim3(kThreads), 0, (hipStream_t)stream,
                        frames, HW, out);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_ingest_depth_u16(const uint16_t* depth, int N, int H, int W, float* out, void* stream) {
+    if (!depth || !out || N <= 0 || N > 65535 || H <= 0 || W <= 0 || (long long)H * W > (1ll << 30)) return DS_ERR_INVALID_ARG;
+    if (((uintptr_t)depth & 3) || ((uintptr_t)out & 7)) return DS_ERR_INVALID_ARG;
+    const size_t n = (size_t)N * H * W, pairs = (n + 1) / 2;
+    hipLaunchKernelGGL(ingest_depth_u16_kernel, dim3((unsigned)((pairs + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, depth, n, out);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

@@ -244,7 +244,24 @@ __device__ __forceinline__ void block_reduce12(float (&gM)[12], float* __restric
 #endif
 constexpr int kBwdRows = DS_BWD_ROWS;  // rows per wave: the 12-float pose-gradient wave reduction is paid once per 8 pixels
 
-template <int C>
+// Image-gradient scatter (IMG): device-scope float atomics are the slow part of the backward with g_src (4 per pixel and
+// channel, ~100 G/s on this part), so each wave first accumulates into its own LDS tile of the source plane -- the
+// footprint of its 64 x kBwdRows target pixels for a near-identity warp, origin taken from its first row -- with LDS
+// atomics, and flushes the non-zero tile elements with one coalesced global atomic each (~1.3 per pixel and channel
+// instead of 4).  Taps that fall outside the tile (large motion, source larger than the grid) go to memory directly.
+constexpr int kTileW = 72, kTileH = kBwdRows + 6, kTileN = 3 * kTileH * kTileW;
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ void lds_add(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int C, bool IMG = false>
 __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restrict__ K, const float* __restrict__ Kinv,
                                                             const float* __restrict__ pose,
                                                             const float* __restrict__ depth,
@@ -253,10 +270,19 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
                                                             float* __restrict__ g_depth, float* __restrict__ g_src,
                                                             float* __restrict__ partials) {
     __shared__ float lds[kThreads / 64][12];
+    __shared__ __attribute__((aligned(16))) float tiles[IMG ? kThreads / 64 : 1][IMG ? kTileN : 4];
     const int n = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int bx = blockIdx.x % G.nbx, by = blockIdx.x / G.nbx;
     const int yb = (by * (kThreads / 64) + wave) * kBwdRows;
+    float* const tile = tiles[IMG ? wave : 0];
+    int ox = 0, oy = 0;  // tile origin in the source plane (wave-uniform)
+    if (IMG) {
+        static_assert(kTileN % 4 == 0, "the tile is cleared in float4 units");
+        for (int e = lane * 4; e < kTileN; e += 64 * 4) *reinterpret_cast<float4*>(tile + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     const int x = bx * 64 + lane, xc = min(x, G.W - 1);
     const int Cc = C > 0 ? C : Cdyn;
     const unsigned HW = (unsigned)(G.H * G.W), HsWs = (unsigned)(G.Hs * G.Ws);
@@ -303,7 +329,33 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
         } else {
             for (int c = 0; c < Cc; ++c) channel(c, buf_load_f32(gp, xb, c * HW + ro));
         }
-        if (g_src && x < G.W) {  // optional image gradient: float atomics (off in the reference's own use)
+        if (IMG) {
+            if (i == 0) {
+                ox = max(wave_min_i(t.xl) - 3, 0);
+                oy = max(wave_min_i(t.y0) - 2, 0);
+            }
+            if (x < G.W) {
+                const int tx = t.xl - ox, ty0 = t.y0 - oy, ty1 = t.y1 - oy;
+                const bool in = tx >= 0 && tx + 1 < kTileW && ty0 >= 0 && ty1 < kTileH;  // ty1 >= ty0
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float gc = g[c];
+                    if (in) {
+                        float* tp = tile + c * (kTileH * kTileW) + tx;
+                        lds_add(tp + ty0 * kTileW, gc * t.wa_t);
+                        lds_add(tp + ty0 * kTileW + 1, gc * t.wb_t);
+                        lds_add(tp + ty1 * kTileW, gc * t.wa_b);
+                        lds_add(tp + ty1 * kTileW + 1, gc * t.wb_b);
+                    } else if (gc != 0.0f) {
+                        float* gp = g_src + ((size_t)n * C + c) * HsWs;
+                        if (t.wa_t != 0.0f) atomicAdd(gp + (t.o_top >> 2), gc * t.wa_t);
+                        if (t.wb_t != 0.0f) atomicAdd(gp + (t.o_top >> 2) + 1, gc * t.wb_t);
+                        if (t.wa_b != 0.0f) atomicAdd(gp + (t.o_bot >> 2), gc * t.wa_b);
+                        if (t.wb_b != 0.0f) atomicAdd(gp + (t.o_bot >> 2) + 1, gc * t.wb_b);
+                    }
+                }
+            }
+        } else if (g_src && x < G.W) {  // generic channel count: float atomics straight to memory
             Samp s;
             sample_setup(pr.u, pr.v, G.Hs, G.Ws, s);
             Corners co;
@@ -332,6 +384,17 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
             gM[4 * j + 3] += gT[j];
         }
         if (x < G.W) buf_store_f32(gd, op, (unsigned)x * 4u, ro * 4u);
+    }
+    if (IMG) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int e = lane; e < kTileN; e += 64) {
+            const float v = tile[e];
+            const int c = e / (kTileH * kTileW), r = e - c * (kTileH * kTileW);
+            const int ty = r / kTileW, gy = oy + ty, gx = ox + (r - ty * kTileW);
+            if (v != 0.0f && gy < G.Hs && gx < G.Ws) atomicAdd(g_src + ((size_t)n * C + c) * HsWs + (size_t)gy * G.Ws + gx, v);
+        }
     }
     block_reduce12(gM, partials + ((size_t)n * gridDim.x + blockIdx.x) * 12, lds);
 }
@@ -551,9 +614,12 @@ int ds_warp_bwd(const float* K, const float* Kinv, const float* pose, const floa
     const int nblk = warp_tiles(H, W, kBwdRows);
     dim3 g(nblk, N), b(kThreads);
     float* partials = (float*)workspace;
-    if (C == 3)
+    if (C == 3 && g_src)
+        hipLaunchKernelGGL((warp_bwd_kernel<3, true>), g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, g_warped, C,
+                           G, g_depth, g_src, partials);
+    else if (C == 3)
         hipLaunchKernelGGL(warp_bwd_kernel<3>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, g_warped, C, G,
-                           g_depth, g_src, partials);
+                           g_depth, nullptr, partials);
     else
         hipLaunchKernelGGL(warp_bwd_kernel<0>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, g_warped, C, G,
                            g_depth, g_src, partials);

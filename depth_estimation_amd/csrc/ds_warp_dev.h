@@ -16,6 +16,7 @@ struct Tap {
     float wa_t, wb_t, wa_b, wb_b;   // weights of the loaded pairs: (a,b) of the top row, (a,b) of the bottom row
     unsigned o_top, o_bot;          // byte offset of the left texel of each pair inside one source plane
     bool shift;                     // x0 == Ws-1: the pair starts one texel to the left
+    int xl, y0, y1;                 // texel coordinates of the pairs (column of the left texel, the two rows)
 };
 
 // synthesis.synthesize's coordinate handling for one pixel (synthesis.py:49-54): normalise with the SOURCE dims,
@@ -43,6 +44,7 @@ __device__ __forceinline__ void make_tap(float u, float v, const WarpGeom& G, Ta
     t.shift = x0 + 1 >= G.Ws;
     const int xc = t.shift ? x0 - 1 : x0;          // Ws >= 2 (checked on the host)
     const int y1 = y0 + 1 < G.Hs ? y0 + 1 : y0;
+    t.xl = xc; t.y0 = y0; t.y1 = y1;
     t.o_top = (unsigned)(y0 * G.Ws + xc) * 4u;
     t.o_bot = (unsigned)(y1 * G.Ws + xc) * 4u;
     t.wa_t = t.shift ? 0.0f : w_nw;

@@ -25,3 +25,27 @@ def to_tensor(frames: torch.Tensor) -> torch.Tensor:
     out = torch.empty(n, 3, h, w, dtype=torch.float32, device=x.device)
     L.check(L.lib().ds_ingest_u8(x.data_ptr(), n, h, w, out.data_ptr(), L.stream()), "ds_ingest_u8")
     return out[0] if single else out
+
+
+def depth_to_tensor(depth: torch.Tensor) -> torch.Tensor:
+    """Ground-truth depth (dataset.py:116-120): (N,H,W) or (H,W) 16-bit samples of the resized PNG on the GPU (uint16,
+    or int16/int32 holding the same bit patterns / values as PIL modes I;16 and I give them) -> (N,1,H,W) / (1,H,W)
+    float32 = value / 2**16."""
+    if not depth.is_cuda:
+        raise RuntimeError(f"depth_to_tensor expects a CUDA tensor, got {depth.device}")
+    if depth.dtype == torch.int32:
+        if depth.numel() and (int(depth.min()) < 0 or int(depth.max()) > 65535):
+            raise RuntimeError("int32 depth samples must lie in [0, 65535]")
+        depth = depth.to(torch.uint16)
+    elif depth.dtype == torch.int16:
+        depth = depth.view(torch.uint16)
+    elif depth.dtype != torch.uint16:
+        raise RuntimeError(f"depth_to_tensor expects uint16/int16/int32 samples, got {depth.dtype}")
+    single = depth.dim() == 2
+    x = (depth.unsqueeze(0) if single else depth).contiguous()
+    if x.dim() != 3:
+        raise RuntimeError(f"expected (N,H,W) or (H,W), got {tuple(depth.shape)}")
+    n, h, w = x.shape
+    out = torch.empty(n, 1, h, w, dtype=torch.float32, device=x.device)
+    L.check(L.lib().ds_ingest_depth_u16(x.data_ptr(), n, h, w, out.data_ptr(), L.stream()), "ds_ingest_depth_u16")
+    return out[0] if single else out

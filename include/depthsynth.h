@@ -158,6 +158,11 @@ int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, fl
  * frames 4-byte aligned, out 16-byte aligned. */
 int ds_ingest_u8(const uint8_t* frames, int N, int H, int W, float* out, void* stream);
 
+/* Ground-truth depth to the device (dataset.py:116-120): the resized 16-bit PNG samples (N,H,W) uint16 ->
+ * out (N,1,H,W) fp32 = value / 2**16.  depth 4-byte aligned, out 8-byte aligned.  The reference holds no depth PNG
+ * and torchvision is absent here: parity unpinned, checked against the direct statement value / 65536. */
+int ds_ingest_depth_u16(const uint16_t* depth, int N, int H, int W, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

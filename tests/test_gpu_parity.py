@@ -367,6 +367,26 @@ def test_ingest_u8_matches_to_tensor(de):
         de.ingest.to_tensor(odd.to(DEV).float())      # wrong dtype
 
 
+def test_ingest_depth_u16(de):
+    """dataset.py:116-120: 16-bit ground-truth samples / 2**16.  The reference holds no depth PNG and torchvision is not
+    installed: parity unpinned, checked bit-exact against the direct statement on every 16-bit value and a ragged size."""
+    allv = np.arange(65536, dtype=np.uint16).reshape(1, 256, 256)
+    want = allv.astype(np.float32) / np.float32(65536)
+    got = de.ingest.depth_to_tensor(torch.from_numpy(allv).to(DEV))
+    assert got.shape == (1, 1, 256, 256) and np.array_equal(N(got)[:, 0], want)
+    rng = np.random.default_rng(3)
+    odd = rng.integers(0, 65536, (3, 7, 9), dtype=np.uint16)            # odd element count: the tail sample
+    want = odd.astype(np.float32) / np.float32(65536)
+    assert np.array_equal(N(de.ingest.depth_to_tensor(torch.from_numpy(odd).to(DEV)))[:, 0], want)
+    assert np.array_equal(N(de.ingest.depth_to_tensor(torch.from_numpy(odd[2]).to(DEV)))[0], want[2])
+    assert np.array_equal(N(de.ingest.depth_to_tensor(torch.from_numpy(odd.astype(np.int32)).to(DEV)))[:, 0], want)   # PIL mode I
+    assert np.array_equal(N(de.ingest.depth_to_tensor(torch.from_numpy(odd.view(np.int16)).to(DEV)))[:, 0], want)
+    with pytest.raises(RuntimeError):
+        de.ingest.depth_to_tensor(torch.from_numpy(odd))
+    with pytest.raises(RuntimeError):
+        de.ingest.depth_to_tensor(torch.full((2, 2), 70000, dtype=torch.int32, device=DEV))
+
+
 def test_rejects_cpu_tensors_and_bad_shapes(de):
     with pytest.raises(RuntimeError):
         de.metrics.rmse(torch.zeros(1, 1, 4, 4), torch.zeros(1, 1, 4, 4))
