@@ -148,6 +148,30 @@ def test_warp_backward(de, oracle, name):
     assert rel_to_max(N(pose2.grad), N(pose.grad)) < 1e-5
 
 
+@pytest.mark.parametrize("motion", ["subpixel", "disparity", "far"])
+def test_image_gradient_any_motion(de, oracle, motion):
+    """The image-gradient scatter of ds_warp_bwd collects a wave's taps in an LDS tile around its first row and sends the
+    rest to memory directly: the result must not depend on where the taps land.  Sub-pixel motion (all in the tile),
+    depth-dependent disparity of tens of pixels (mixed), everything shifted out of the image (border texels collect)."""
+    S, H, W = 2, 37, 131
+    rng = np.random.default_rng(17)
+    K, Kinv = [a.numpy() for a in de.fused.intrinsics(W, H)]
+    src = rng.random((S, 3, H, W), dtype=np.float32)
+    g_warped = rng.standard_normal((S, 3, H, W)).astype(np.float32)
+    depth = {"subpixel": 1 + 79 * rng.random((S, H, W), dtype=np.float32),
+             "disparity": 1 + 9 * rng.random((S, H, W), dtype=np.float32) ** 3,
+             "far": 1 + 79 * rng.random((S, H, W), dtype=np.float32)}[motion].astype(np.float32)
+    vec = {"subpixel": 0.01 * rng.standard_normal((S, 6)),
+           "disparity": np.array([[0.01, -0.02, 0.005, 0.6, -0.05, 0.2], [-0.01, 0.015, 0.0, -0.5, 0.04, -0.1]]),
+           "far": np.array([[0.3, 0.9, 0.1, 5.0, 1.0, 0.0], [0.0, -0.8, 0.2, -40.0, 3.0, 1.0]])}[motion].astype(np.float32)
+    pm = oracle.pose_from_vec(vec)
+    sr = T(src).requires_grad_(True)
+    de.ops.warp(T(K), T(Kinv), T(pm), T(depth), sr).backward(T(g_warped))
+    want = np.stack([oracle.warp_bwd(K, Kinv, pm[s], depth[s], src[s], g_warped[s], H, W)[2] for s in range(S)])
+    assert np.abs(want).max() > 0
+    assert rel_to_max(N(sr.grad), want) < 1e-4
+
+
 @pytest.mark.parametrize("name", LOSS_CASES)
 def test_reference_call_sequence_end_to_end(de, name):
     """train.py:72-92 written against the drop-in modules, gradients through autograd, vs the reference's
