@@ -5,6 +5,7 @@
 // metrics.rmse/rmsle/abs_rel/sq_rel (metrics.py:100-153).
 #include "ds_common.h"
 #include "ds_warp_dev.h"
+#include <algorithm>
 #include "depthsynth.h"
 
 using namespace ds;
@@ -209,8 +210,8 @@ __device__ __forceinline__ float block_sum(float v, float* lds) {
 }
 
 __global__ __launch_bounds__(kThreads) void smooth_fwd_kernel(const float* __restrict__ depths,
-                                                              const float* __restrict__ targets, int C, int H, int W,
-                                                              float* __restrict__ partials) {
+                                                              const float* __restrict__ targets, int S, int C, int H,
+                                                              int W, float* __restrict__ partials) {
     __shared__ float lds[kThreads / 64];
     const int n = blockIdx.y, HW = H * W;
     const int p = blockIdx.x * kThreads + threadIdx.x;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void smooth_fwd_kernel(const float* __res
         const float adx = fabsf(grad1d(D + y * W, x, W, 1)), ady = fabsf(grad1d(D + x, y, H, W));
         float acc = 0.f;
         for (int c = 0; c < C; ++c) {
-            const float* I = targets + ((size_t)n * C + c) * HW;
+            const float* I = targets + ((size_t)(n / S) * C + c) * HW;
             const float ex = expf(fabsf(grad1d(I + y * W, x, W, 1)));
             const float ey = expf(fabsf(grad1d(I + x, y, H, W)));
             const float t = adx / ex + ady / ey;
@@ -233,12 +234,22 @@ __global__ __launch_bounds__(kThreads) void smooth_fwd_kernel(const float* __res
     if (threadIdx.x == 0) partials[(size_t)n * gridDim.x + blockIdx.x] = s;
 }
 
-__global__ void sum_finalize_kernel(const float* __restrict__ partials, int n, double scale, float* __restrict__ out) {
+constexpr int kSumThreads = 1024;  // one workgroup; fixed summation order (deterministic)
+
+__global__ __launch_bounds__(kSumThreads) void sum_finalize_kernel(const float* __restrict__ partials, int n, double scale,
+                                                                   float* __restrict__ out) {
+    __shared__ double lds[kSumThreads / 64];
     double a = 0.0;
-    for (int i = threadIdx.x; i < n; i += 64) a += (double)partials[i];
+    for (int i = threadIdx.x; i < n; i += kSumThreads) a += (double)partials[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    if (threadIdx.x == 0) out[0] = (float)(a * scale);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kSumThreads / 64; ++w) t += lds[w];
+        out[0] = (float)(t * scale);
+    }
 }
 
 // q = d(term)/d(ddx) at pixel (y,x): upstream * sign(ddx) * sum_c exp(-|dI_c|) / C   (x direction; y alike)
@@ -269,14 +280,14 @@ __device__ __forceinline__ float grad1d_adjoint(float qm, float q0, float qp, in
 
 __global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(const float* __restrict__ depths,
                                                               const float* __restrict__ targets,
-                                                              const float* __restrict__ g_value, int N, int C, int H, int W,
-                                                              float* __restrict__ g_depths) {
+                                                              const float* __restrict__ g_value, int N, int S, int C, int H,
+                                                              int W, float* __restrict__ g_depths) {
     const int n = blockIdx.y, HW = H * W;
     const int p = blockIdx.x * kThreads + threadIdx.x;
     if (p >= HW) return;
     const int y = p / W, x = p - y * W;
     const float* D = depths + (size_t)n * HW;
-    const float* T = targets + (size_t)n * C * HW;
+    const float* T = targets + (size_t)(n / S) * C * HW;
     const float g = g_value[0] / ((float)N * (float)HW) / (float)C;
     float qx0, qy0, qxm = 0.f, qxp = 0.f, qym = 0.f, qyp = 0.f, dummy;
     smooth_q(D, T, C, H, W, y, x, g, qx0, qy0);
@@ -287,36 +298,219 @@ __global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(const float* __res
     g_depths[(size_t)n * HW + p] = grad1d_adjoint(qxm, qx0, qxp, x, W) + grad1d_adjoint(qym, qy0, qyp, y, H);
 }
 
+// ---- tiled smoothness for C == 3 ------------------------------------------------------------------
+// The generic kernels above evaluate 6 (forward) or 30 (backward) exp + divide pairs per pixel and map.  Here a wave
+// owns 64 columns x kSmoothRows rows of ONE target and rolls down the rows with the previous / current / next row of the
+// three target channels and of its S depth maps in registers (left / right neighbours are two more coalesced loads per
+// row).  The edge weights Wx = sum_c exp(-|dI_c/dx|), Wy alike, are formed once per target pixel and shared by the S
+// maps of that target (the reference stacks the target S times, train.py:80-83): a map costs two differences and two
+// fma on top.  sum_c |dd|/exp(|dI_c|) = |dd| * sum_c exp(-|dI_c|) is a re-association: the value is a mean over all
+// pixels with a 1e-4 relative bar, not a bit-exact map.  torch.gradient's one-sided edges are the same
+// difference of clamped neighbours with scale 1 instead of 1/2.
+constexpr int kSmoothRows = 8;      // forward: rows per wave
+constexpr int kSmoothBwdRows = 16;  // backward: rows per wave (two extra rows of q on top)
+constexpr int kSmoothMaxS = 4;      // maps of one target per pass
+
+struct SmoothGeom { int H, W, nbx, S, s0, sn; };  // S maps per target; this launch handles maps s0 .. s0+sn-1 of each
+
+__device__ __forceinline__ float edge_scale(int i, int L) { return (i == 0 || i == L - 1) ? 1.0f : 0.5f; }
+__device__ __forceinline__ float neg_exp(float a) { return __builtin_amdgcn_exp2f(a * -1.4426950408889634f); }
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.0f : (v < 0.f ? -1.0f : 0.0f); }
+
+template <int S>
+__global__ __launch_bounds__(kThreads) void smooth_tiled_fwd_kernel(const float* __restrict__ depths,
+                                                                    const float* __restrict__ targets, SmoothGeom G,
+                                                                    float* __restrict__ partials) {
+    const int t = blockIdx.y, HW = G.H * G.W;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int bx = blockIdx.x % G.nbx, by = blockIdx.x / G.nbx;
+    const int ya = (by * (kThreads / 64) + wave) * kSmoothRows, yb = min(ya + kSmoothRows, G.H);
+    const int x = bx * 64 + lane, xc = min(x, G.W - 1), xl = max(xc - 1, 0), xr = min(xc + 1, G.W - 1);
+    const float sx = edge_scale(xc, G.W);
+    const float* I = targets + (size_t)t * 3 * HW;
+    const float* D = depths + ((size_t)t * G.S + G.s0) * HW;
+    float acc = 0.f;
+    if (ya < G.H) {
+        float ic[3][3], dc[S][3];  // [.][0..2] = rows r-1, r, r+1 (clamped) at column xc
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ic[c][1] = I[c * HW + max(ya - 1, 0) * G.W + xc];
+            ic[c][2] = I[c * HW + ya * G.W + xc];
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            dc[s][1] = D[s * HW + max(ya - 1, 0) * G.W + xc];
+            dc[s][2] = D[s * HW + ya * G.W + xc];
+        }
+        for (int r = ya; r < yb; ++r) {
+            const int rn = min(r + 1, G.H - 1) * G.W, ro = r * G.W;
+            const float sy = edge_scale(r, G.H);
+            float wx = 0.f, wy = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                ic[c][0] = ic[c][1];
+                ic[c][1] = ic[c][2];
+                ic[c][2] = I[c * HW + rn + xc];
+                wx += neg_exp(fabsf(I[c * HW + ro + xr] - I[c * HW + ro + xl]) * sx);
+                wy += neg_exp(fabsf(ic[c][2] - ic[c][0]) * sy);
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                dc[s][0] = dc[s][1];
+                dc[s][1] = dc[s][2];
+                dc[s][2] = D[s * HW + rn + xc];
+                const float adx = fabsf(D[s * HW + ro + xr] - D[s * HW + ro + xl]) * sx;
+                const float ady = fabsf(dc[s][2] - dc[s][0]) * sy;
+                acc += fmaf(adx, wx, ady * wy);
+            }
+        }
+        if (x >= G.W) acc = 0.f;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) partials[((size_t)t * gridDim.x + blockIdx.x) * (kThreads / 64) + wave] = acc;
+}
+
+// Backward: d value / d depth.  With q = g * W * sign(dd) * scale at every pixel (g = upstream / (N*H*W*3)), the adjoint
+// of torch.gradient along a line is q[j-1] - q[j+1], where a neighbour beyond the end of the line is replaced by -q[j].
+// A wave covers 62 columns plus one halo lane on either side (the x neighbours of q come from a lane shuffle) and rolls
+// over rows ya-1 .. yb: q of row r is formed when row r+1 is in registers, the output row r-1 is written then.
+template <int S>
+__global__ __launch_bounds__(kThreads) void smooth_tiled_bwd_kernel(const float* __restrict__ depths,
+                                                                    const float* __restrict__ targets,
+                                                                    const float* __restrict__ g_value, float inv_count,
+                                                                    SmoothGeom G, float* __restrict__ g_depths) {
+    const int t = blockIdx.y, HW = G.H * G.W;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int bx = blockIdx.x % G.nbx, by = blockIdx.x / G.nbx;
+    const int ya = (by * (kThreads / 64) + wave) * kSmoothBwdRows, yb = min(ya + kSmoothBwdRows, G.H);
+    if (ya >= G.H) return;
+    const int x = bx * 62 - 1 + lane, xc = min(max(x, 0), G.W - 1), xl = max(xc - 1, 0), xr = min(xc + 1, G.W - 1);
+    const bool store = lane >= 1 && lane <= 62 && x < G.W;
+    const float sx = edge_scale(xc, G.W);
+    const float g = g_value[0] * inv_count;
+    const float* I = targets + (size_t)t * 3 * HW;
+    const float* D = depths + ((size_t)t * G.S + G.s0) * HW;
+    float* O = g_depths + ((size_t)t * G.S + G.s0) * HW;
+    auto row_of = [&](int r) { return min(max(r, 0), G.H - 1) * G.W; };
+    float ic[3][3], dc[S][3], qy[S][2], gx[S];  // qy[.][0], [1] = q_y of rows r-2, r-1; gx = x part of output row r-1
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        ic[c][1] = I[c * HW + row_of(ya - 2) + xc];
+        ic[c][2] = I[c * HW + row_of(ya - 1) + xc];
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        dc[s][1] = D[s * HW + row_of(ya - 2) + xc];
+        dc[s][2] = D[s * HW + row_of(ya - 1) + xc];
+        qy[s][0] = qy[s][1] = 0.f;
+        gx[s] = 0.f;
+    }
+    for (int r = ya - 1; r <= yb; ++r) {
+        const bool live = r >= 0 && r < G.H;  // wave-uniform
+        const int rn = row_of(r + 1), ro = row_of(r);
+        const float sy = edge_scale(r, G.H);
+        float wx = 0.f, wy = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ic[c][0] = ic[c][1];
+            ic[c][1] = ic[c][2];
+            ic[c][2] = I[c * HW + rn + xc];
+            wx += neg_exp(fabsf(I[c * HW + ro + xr] - I[c * HW + ro + xl]) * sx);
+            wy += neg_exp(fabsf(ic[c][2] - ic[c][0]) * sy);
+        }
+        const int y = r - 1;  // the output row of this iteration
+        const bool emit = y >= ya && y < yb;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            dc[s][0] = dc[s][1];
+            dc[s][1] = dc[s][2];
+            dc[s][2] = D[s * HW + rn + xc];
+            float qx = g * wx * sgn(D[s * HW + ro + xr] - D[s * HW + ro + xl]) * sx;
+            float qyn = g * wy * sgn(dc[s][2] - dc[s][0]) * sy;
+            if (!live) qx = qyn = 0.f;
+            const float ql = __shfl_up(qx, 1, 64), qr = __shfl_down(qx, 1, 64);
+            const float gxn = (xc >= 1 ? ql : -qx) - (xc <= G.W - 2 ? qr : -qx);
+            if (emit && store) {
+                const float up = y >= 1 ? qy[s][0] : -qy[s][1];
+                const float down = y <= G.H - 2 ? qyn : -qy[s][1];
+                O[s * HW + y * G.W + x] = gx[s] + (up - down);
+            }
+            qy[s][0] = qy[s][1];
+            qy[s][1] = qyn;
+            gx[s] = gxn;
+        }
+    }
+}
+
+inline int smooth_fwd_blocks(int H, int W) {
+    const int per = (kThreads / 64) * kSmoothRows;
+    return ((W + 63) / 64) * ((H + per - 1) / per);
+}
+inline int smooth_bwd_blocks(int H, int W) {
+    const int per = (kThreads / 64) * kSmoothBwdRows;
+    return ((W + 61) / 62) * ((H + per - 1) / per);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // a11-a15: all depth metrics in one pass
 // ---------------------------------------------------------------------------------------------------
-constexpr int kMetPix = 8;  // pixels per thread
+constexpr int kMetPix = 8;  // pixels per thread: two 16-byte loads of each map
+
+// One valid-or-not pixel into the eight running sums.  The four quotients (|d|/g, d^2/g, p/g, g/p) are IEEE divides; for
+// operands of ordinary magnitude they come bit-identically from one refined reciprocal per denominator (div_by,
+// ds_common.h: 5 instructions each instead of ~12), anything else takes the plain divide.
+__device__ __forceinline__ void metrics_pixel(float p, float g, float (&a)[8]) {
+    if (!(g > 0.0f)) return;
+    const float df = p - g, sq = df * df, ad = fabsf(df), ap = fabsf(p);
+    const float lg = logf(p + 1e-6f) - logf(g + 1e-6f);
+    float q_ad, q_sq, q_pg, q_gp;
+    if (g > 1e-15f && g < 1e15f && ap > 1e-15f && ap < 1e15f) {
+        const float rg = rcp_refined(g), rp = rcp_refined(p);
+        q_ad = div_by(ad, g, rg);
+        q_sq = div_by(sq, g, rg);
+        q_pg = div_by(p, g, rg);
+        q_gp = div_by(g, p, rp);
+    } else {
+        q_ad = ad / g;
+        q_sq = sq / g;
+        q_pg = p / g;
+        q_gp = g / p;
+    }
+    a[0] += sq;
+    a[1] += lg * lg;
+    a[2] += q_ad;
+    a[3] += q_sq;
+    const float r = fmaxf(q_pg, q_gp);
+    a[4] += r < 1.25f ? 1.f : 0.f;
+    a[5] += r < 1.5625f ? 1.f : 0.f;
+    a[6] += r < 1.953125f ? 1.f : 0.f;
+    a[7] += 1.f;
+}
 
 __global__ __launch_bounds__(kThreads) void metrics_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
-                                                           int HW, float* __restrict__ partials) {
+                                                           int HW, int vec, float* __restrict__ partials) {
     __shared__ float lds[8][kThreads / 64];
     const int b = blockIdx.y;
     float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const float* P = pred + (size_t)b * HW;
     const float* G = gt + (size_t)b * HW;
+    const int base = blockIdx.x * (kMetPix * kThreads);
+    if (vec && base + kMetPix * kThreads <= HW) {
+        // whole block inside the image; vec: every image starts 16-byte aligned (HW % 4 == 0 and aligned bases)
 #pragma unroll
-    for (int it = 0; it < kMetPix; ++it) {
-        const int i = (blockIdx.x * kMetPix + it) * kThreads + threadIdx.x;
-        if (i < HW) {
-            const float p = P[i], g = G[i];
-            if (g > 0.0f) {
-                const float df = p - g, sq = df * df;
-                const float lg = logf(p + 1e-6f) - logf(g + 1e-6f);
-                a[0] += sq;
-                a[1] += lg * lg;
-                a[2] += fabsf(df) / g;
-                a[3] += sq / g;
-                const float r = fmaxf(p / g, g / p);
-                a[4] += r < 1.25f ? 1.f : 0.f;
-                a[5] += r < 1.5625f ? 1.f : 0.f;
-                a[6] += r < 1.953125f ? 1.f : 0.f;
-                a[7] += 1.f;
-            }
+        for (int it = 0; it < kMetPix / 4; ++it) {
+            const int i = base + (it * kThreads + threadIdx.x) * 4;
+            const float4 p = *reinterpret_cast<const float4*>(P + i), g = *reinterpret_cast<const float4*>(G + i);
+            metrics_pixel(p.x, g.x, a);
+            metrics_pixel(p.y, g.y, a);
+            metrics_pixel(p.z, g.z, a);
+            metrics_pixel(p.w, g.w, a);
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < kMetPix; ++it) {
+            const int i = base + it * kThreads + threadIdx.x;
+            if (i < HW) metrics_pixel(P[i], G[i], a);
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -334,25 +528,43 @@ __global__ __launch_bounds__(kThreads) void metrics_kernel(const float* __restri
 }
 
 // partials (B, nblk, 8) -> out (8): per-image finalisation then mean over B (metrics.py:111,125,139,153)
-__global__ void metrics_finalize_kernel(const float* __restrict__ partials, int B, int nblk, double inv_hw,
-                                        float* __restrict__ out) {
+// One workgroup of kFinWaves waves: wave w takes the images w, w + kFinWaves, ...; its lanes split the image's block
+// partials (two 16-byte loads each), sums in double, fixed order throughout (deterministic).
+constexpr int kFinWaves = 16;
+
+__global__ __launch_bounds__(kFinWaves * 64) void metrics_finalize_kernel(const float* __restrict__ partials, int B, int nblk,
+                                                                          double inv_hw, float* __restrict__ out) {
+    __shared__ double lds[kFinWaves][8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int b = threadIdx.x; b < B; b += 64) {
+    for (int b = wave; b < B; b += kFinWaves) {
         double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int j = 0; j < nblk; ++j)
-            for (int k = 0; k < 8; ++k) s[k] += (double)partials[((size_t)b * nblk + j) * 8 + k];
+        for (int j = lane; j < nblk; j += 64) {
+            const float4* q = reinterpret_cast<const float4*>(partials + ((size_t)b * nblk + j) * 8);
+            const float4 lo = q[0], hi = q[1];
+            s[0] += (double)lo.x; s[1] += (double)lo.y; s[2] += (double)lo.z; s[3] += (double)lo.w;
+            s[4] += (double)hi.x; s[5] += (double)hi.y; s[6] += (double)hi.z; s[7] += (double)hi.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_xor(s[k], o, 64);
+        }
         acc[0] += sqrt(s[0] * inv_hw);
         acc[1] += sqrt(s[1] * inv_hw);
+#pragma unroll
         for (int k = 2; k < 7; ++k) acc[k] += s[k] * inv_hw;
         acc[7] += s[7];
     }
-    for (int k = 0; k < 8; ++k) {
+    if (lane == 0) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+        for (int k = 0; k < 8; ++k) lds[wave][k] = acc[k];
     }
-    if (threadIdx.x == 0) {
-        for (int k = 0; k < 7; ++k) out[k] = (float)(acc[k] / (double)B);
-        out[7] = (float)acc[7];
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        double t = 0.0;
+        for (int w = 0; w < kFinWaves; ++w) t += lds[w][threadIdx.x];
+        out[threadIdx.x] = threadIdx.x < 7 ? (float)(t / (double)B) : (float)t;
     }
 }
 
@@ -533,7 +745,9 @@ static int plane_sweep_launch(const float* K, const float* Kinv, const float* po
                               int sid, float* depth, void* stream) {
     Planes pl;
     if (!K || !Kinv || !pose || !src || !targets || !depth || B <= 0 || S <= 0 || (long long)B * S > 65535 ||
-        bad_img(B * S, C, H, W) || Hs < 2 || Ws < 2 || !fill_planes(pl, depths_host, D))
+        bad_img(B * S, C, H, W) || Hs < 2 || Ws < 2 || (long long)Hs * Ws > (1ll << 30) ||
+        (long long)C * H * W * 4 >= (1ll << 32) || (long long)C * Hs * Ws * 4 >= (1ll << 32) ||  // 32-bit byte offsets
+        !fill_planes(pl, depths_host, D))
         return DS_ERR_INVALID_ARG;
     const WarpGeom G = warp_geom(Hs, Ws, H, W);
     dim3 grid(G.nbx * ((H + kThreads / 64 - 1) / (kThreads / 64)), B * S), blk(kThreads);
@@ -561,30 +775,84 @@ int ds_plane_sweep_depth_batch(const float* K, const float* Kinv, const float* p
 
 size_t ds_smooth_workspace_bytes(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)N * pix_blocks(H * W) * sizeof(float);
+    // one float per workgroup (generic kernel) or per wave (tiled kernel), whichever is more, for every map
+    const size_t per_map = (size_t)std::max(pix_blocks(H * W), smooth_fwd_blocks(H, W) * (kThreads / 64));
+    return (size_t)N * per_map * sizeof(float);
+}
+
+int ds_smooth_batch_fwd(const float* depths, const float* targets, int B, int S, int C, int H, int W, float* value,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!depths || !targets || !value || B <= 0 || S <= 0 || (long long)B * S > 65535 || bad_img(B * S, C, H, W))
+        return DS_ERR_INVALID_ARG;
+    const int N = B * S;
+    if (!workspace || workspace_bytes < ds_smooth_workspace_bytes(N, H, W)) return DS_ERR_WORKSPACE;
+    float* partials = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    if (C != 3) {
+        const int nb = pix_blocks(H * W);
+        hipLaunchKernelGGL(smooth_fwd_kernel, dim3(nb, N), dim3(kThreads), 0, st, depths, targets, S, C, H, W, partials);
+        DS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(kSumThreads), 0, st, partials, nb * N, 1.0 / ((double)N * H * W),
+                           value);
+        DS_CHECK_LAUNCH();
+        return DS_OK;
+    }
+    const int nblk = smooth_fwd_blocks(H, W), per_pass = B * nblk * (kThreads / 64);
+    int passes = 0;
+    for (int s0 = 0; s0 < S; s0 += kSmoothMaxS, ++passes) {
+        const SmoothGeom G{H, W, (W + 63) / 64, S, s0, std::min(kSmoothMaxS, S - s0)};
+        float* out = partials + (size_t)passes * per_pass;
+        dim3 grid(nblk, B), blk(kThreads);
+        switch (G.sn) {
+            case 1: hipLaunchKernelGGL(smooth_tiled_fwd_kernel<1>, grid, blk, 0, st, depths, targets, G, out); break;
+            case 2: hipLaunchKernelGGL(smooth_tiled_fwd_kernel<2>, grid, blk, 0, st, depths, targets, G, out); break;
+            case 3: hipLaunchKernelGGL(smooth_tiled_fwd_kernel<3>, grid, blk, 0, st, depths, targets, G, out); break;
+            default: hipLaunchKernelGGL(smooth_tiled_fwd_kernel<4>, grid, blk, 0, st, depths, targets, G, out); break;
+        }
+        DS_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(kSumThreads), 0, st, partials, passes * per_pass,
+                       1.0 / ((double)N * H * W * 3.0), value);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+int ds_smooth_batch_bwd(const float* depths, const float* targets, const float* g_value, int B, int S, int C, int H, int W,
+                        float* g_depths, void* stream) {
+    if (!depths || !targets || !g_value || !g_depths || B <= 0 || S <= 0 || (long long)B * S > 65535 ||
+        bad_img(B * S, C, H, W))
+        return DS_ERR_INVALID_ARG;
+    const int N = B * S;
+    hipStream_t st = (hipStream_t)stream;
+    if (C != 3) {
+        hipLaunchKernelGGL(smooth_bwd_kernel, dim3(pix_blocks(H * W), N), dim3(kThreads), 0, st, depths, targets, g_value, N, S,
+                           C, H, W, g_depths);
+        DS_CHECK_LAUNCH();
+        return DS_OK;
+    }
+    const float inv_count = (float)(1.0 / ((double)N * H * W * 3.0));
+    for (int s0 = 0; s0 < S; s0 += kSmoothMaxS) {
+        const SmoothGeom G{H, W, (W + 61) / 62, S, s0, std::min(kSmoothMaxS, S - s0)};
+        dim3 grid(smooth_bwd_blocks(H, W), B), blk(kThreads);
+        switch (G.sn) {
+            case 1: hipLaunchKernelGGL(smooth_tiled_bwd_kernel<1>, grid, blk, 0, st, depths, targets, g_value, inv_count, G, g_depths); break;
+            case 2: hipLaunchKernelGGL(smooth_tiled_bwd_kernel<2>, grid, blk, 0, st, depths, targets, g_value, inv_count, G, g_depths); break;
+            case 3: hipLaunchKernelGGL(smooth_tiled_bwd_kernel<3>, grid, blk, 0, st, depths, targets, g_value, inv_count, G, g_depths); break;
+            default: hipLaunchKernelGGL(smooth_tiled_bwd_kernel<4>, grid, blk, 0, st, depths, targets, g_value, inv_count, G, g_depths); break;
+        }
+        DS_CHECK_LAUNCH();
+    }
+    return DS_OK;
 }
 
 int ds_smooth_fwd(const float* depths, const float* targets, int N, int C, int H, int W, float* value, void* workspace,
                   size_t workspace_bytes, void* stream) {
-    if (!depths || !targets || !value || bad_img(N, C, H, W)) return DS_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < ds_smooth_workspace_bytes(N, H, W)) return DS_ERR_WORKSPACE;
-    const int nb = pix_blocks(H * W);
-    hipLaunchKernelGGL(smooth_fwd_kernel, dim3(nb, N), dim3(kThreads), 0, (hipStream_t)stream, depths, targets, C, H, W,
-                       (float*)workspace);
-    DS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, nb * N,
-                       1.0 / ((double)N * H * W), value);
-    DS_CHECK_LAUNCH();
-    return DS_OK;
+    return ds_smooth_batch_fwd(depths, targets, N, 1, C, H, W, value, workspace, workspace_bytes, stream);
 }
 
 int ds_smooth_bwd(const float* depths, const float* targets, const float* g_value, int N, int C, int H, int W,
                   float* g_depths, void* stream) {
-    if (!depths || !targets || !g_value || !g_depths || bad_img(N, C, H, W)) return DS_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(smooth_bwd_kernel, dim3(pix_blocks(H * W), N), dim3(kThreads), 0, (hipStream_t)stream, depths, targets,
-                       g_value, N, C, H, W, g_depths);
-    DS_CHECK_LAUNCH();
-    return DS_OK;
+    return ds_smooth_batch_bwd(depths, targets, g_value, N, 1, C, H, W, g_depths, stream);
 }
 
 size_t ds_metrics_workspace_bytes(int B, int H, int W) {
@@ -595,11 +863,14 @@ size_t ds_metrics_workspace_bytes(int B, int H, int W) {
 int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, float* out, void* workspace,
                      size_t workspace_bytes, void* stream) {
     if (!pred || !gt || !out || bad_img(B, 1, H, W)) return DS_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < ds_metrics_workspace_bytes(B, H, W)) return DS_ERR_WORKSPACE;
+    if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ds_metrics_workspace_bytes(B, H, W))
+        return DS_ERR_WORKSPACE;
     const int nb = metric_blocks(H * W);
-    hipLaunchKernelGGL(metrics_kernel, dim3(nb, B), dim3(kThreads), 0, (hipStream_t)stream, pred, gt, H * W, (float*)workspace);
+    const int vec = ((H * W) & 3) == 0 && (((uintptr_t)pred | (uintptr_t)gt) & 15) == 0;
+    hipLaunchKernelGGL(metrics_kernel, dim3(nb, B), dim3(kThreads), 0, (hipStream_t)stream, pred, gt, H * W, vec,
+                       (float*)workspace);
     DS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, B, nb,
+    hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(kFinWaves * 64), 0, (hipStream_t)stream, (const float*)workspace, B, nb,
                        1.0 / ((double)H * W), out);
     DS_CHECK_LAUNCH();
     return DS_OK;

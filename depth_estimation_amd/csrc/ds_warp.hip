@@ -543,7 +543,9 @@ inline int warp_tiles(int H, int W, int rows) {  // blocks per image: 64 columns
 
 inline bool bad_dims(int N, int C, int Hs, int Ws, int H, int W) {
     return N <= 0 || C <= 0 || Hs < 2 || Ws < 2 || H <= 0 || W <= 0 || N > 65535 ||
-           (long long)H * W > (1ll << 30) || (long long)Hs * Ws > (1ll << 30);
+           (long long)H * W > (1ll << 30) || (long long)Hs * Ws > (1ll << 30) ||
+           // the tiled kernels address the C planes of one image with 32-bit byte offsets
+           (long long)C * H * W * 4 >= (1ll << 32) || (long long)C * Hs * Ws * 4 >= (1ll << 32);
 }
 
 }  // namespace

@@ -42,11 +42,10 @@ def train_step_loss(src, target, depth, pose, K, Kinv, max_depth: float = 80.0, 
     r = fused_reprojection_loss(src, target, depth, pose, K, Kinv)
     loss = r["loss"].sum()
     h, w = target.shape[-2:]
-    tg = target.unsqueeze(1).expand(b, s, 3, h, w).reshape(b * s, 3, h, w).contiguous()
     # the reference's regularization mean is per sample (N = S maps of H*W pixels each, train.py:83) and the samples
     # are summed (train.py:89): every sample has the same pixel count, so the sum of the per-sample means is
-    # B x the mean over all B*S maps -- one launch instead of B
-    loss = loss + (smooth_weight * b) * ops.smoothness((depth / max_depth).reshape(b * s, 1, h, w), tg)
+    # B x the mean over all B*S maps -- one launch instead of B, and the S maps of a target share its edge weights
+    loss = loss + (smooth_weight * b) * ops.smoothness((depth / max_depth).reshape(b * s, 1, h, w), target)
     r["total"] = loss
     return r
 

@@ -306,14 +306,16 @@ class _Smooth(torch.autograd.Function):
     def forward(ctx, depths, targets):
         depths, targets = L.dev_f32(depths, "depths"), L.dev_f32(targets, "target_imgs")
         L.same_device(depths, targets)
-        n, c, h, w = targets.shape
-        if depths.shape != (n, 1, h, w):
-            raise RuntimeError(f"depths must be ({n},1,{h},{w}), got {tuple(depths.shape)}")
+        b, c, h, w = targets.shape
+        n = depths.shape[0]
+        if depths.dim() != 4 or depths.shape[1:] != (1, h, w) or n == 0 or n % b:
+            raise RuntimeError(f"depths must be (k*{b},1,{h},{w}), got {tuple(depths.shape)}")
+        s = n // b
         val = torch.empty(1, dtype=torch.float32, device=depths.device)
         nb = L.lib().ds_smooth_workspace_bytes(n, h, w)
         ws = L.workspace.get(nb, depths.device)
-        L.check(L.lib().ds_smooth_fwd(depths.data_ptr(), targets.data_ptr(), n, c, h, w, val.data_ptr(), ws.data_ptr(), nb,
-                                      L.stream()), "ds_smooth_fwd")
+        L.check(L.lib().ds_smooth_batch_fwd(depths.data_ptr(), targets.data_ptr(), b, s, c, h, w, val.data_ptr(),
+                                            ws.data_ptr(), nb, L.stream()), "ds_smooth_batch_fwd")
         ctx.save_for_backward(depths, targets)
         return val.reshape(())
 
@@ -322,15 +324,18 @@ class _Smooth(torch.autograd.Function):
         depths, targets = ctx.saved_tensors
         if ctx.needs_input_grad[1]:
             raise RuntimeError("regularization_term: gradient w.r.t. target_imgs is not implemented")
-        n, c, h, w = targets.shape
+        b, c, h, w = targets.shape
+        s = depths.shape[0] // b
         g = L.dev_f32(g.reshape(1), "grad")
         gd = torch.empty_like(depths)
-        L.check(L.lib().ds_smooth_bwd(depths.data_ptr(), targets.data_ptr(), g.data_ptr(), n, c, h, w, gd.data_ptr(),
-                                      L.stream()), "ds_smooth_bwd")
+        L.check(L.lib().ds_smooth_batch_bwd(depths.data_ptr(), targets.data_ptr(), g.data_ptr(), b, s, c, h, w,
+                                            gd.data_ptr(), L.stream()), "ds_smooth_batch_bwd")
         return gd, None
 
 
 def smoothness(depths, targets) -> torch.Tensor:
+    """metrics.regularization_term (metrics.py:75-97): depths (N,1,H,W), targets (N,C,H,W) -> scalar.  With targets
+    (B,C,H,W) and N = B*S the S maps b*S..b*S+S-1 share target b (the stack of train.py:80 left implicit)."""
     return _Smooth.apply(depths, targets)
 
 

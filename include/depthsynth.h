@@ -145,10 +145,17 @@ int ds_smooth_fwd(const float* depths, const float* targets, int N, int C, int H
 /* g_value (1, device) -> g_depths (N,1,H,W) */
 int ds_smooth_bwd(const float* depths, const float* targets, const float* g_value, int N, int C, int H, int W,
                   float* g_depths, void* stream);
+/* The same with the target stack of train.py:80-83 left implicit: depths (B*S,1,H,W), the S maps of target b at rows
+ * b*S..b*S+S-1, targets (B,C,H,W) -> mean over all B*S maps (= the reference's value when called per sample with
+ * equal-sized samples, see fused.train_step_loss).  workspace from ds_smooth_workspace_bytes(B*S, H, W). */
+int ds_smooth_batch_fwd(const float* depths, const float* targets, int B, int S, int C, int H, int W, float* value,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int ds_smooth_batch_bwd(const float* depths, const float* targets, const float* g_value, int B, int S, int C, int H, int W,
+                        float* g_depths, void* stream);
 
 /* metrics.rmse / rmsle / abs_rel / sq_rel (metrics.py:100-153; test.py:78-81) in ONE pass over
  * pred, gt (B,1,H,W): out (8) fp32 = rmse, rmsle, abs_rel, sq_rel, delta<1.25, <1.25^2, <1.25^3 (not in
- * the reference: same all-pixel denominator, parity unpinned), number of valid pixels. */
+ * the reference: same all-pixel denominator, parity unpinned), number of valid pixels.  workspace 16-byte aligned. */
 size_t ds_metrics_workspace_bytes(int B, int H, int W);
 int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, float* out, void* workspace,
                      size_t workspace_bytes, void* stream);

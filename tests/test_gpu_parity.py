@@ -346,6 +346,31 @@ def test_smoothness(de, oracle):
         assert rel_to_max(N(dep.grad), d["g_depth_reg"]) < 1e-4
 
 
+@pytest.mark.parametrize("B,S,C,H,W", [(2, 1, 3, 37, 131), (3, 2, 3, 40, 72), (1, 5, 3, 33, 63), (2, 3, 3, 2, 2),
+                                       (1, 2, 3, 70, 125), (2, 2, 1, 19, 37), (1, 1, 3, 17, 1)])
+def test_smoothness_batch_forms(de, oracle, B, S, C, H, W):
+    """metrics.regularization_term with the target stack implicit (targets (B,C,H,W) for B*S maps) == the stacked call ==
+    the oracle (metrics.py:75-97), value and depth gradient to 1e-4; sizes around the 64/62-column and 8/16-row tiles,
+    more maps per target than one pass takes, a channel count that takes the generic kernels, a one-column image."""
+    rng = np.random.default_rng(B * 1000 + S * 100 + H)
+    dep = (rng.random((B * S, 1, H, W), dtype=np.float32) + 0.01).astype(np.float32)
+    tgt = rng.random((B, C, H, W), dtype=np.float32)
+    stacked = np.repeat(tgt, S, axis=0)
+    if H > 1 and W > 1:
+        want, g_want = oracle.regularization_term(dep, stacked, want_grad=True)
+    d1 = T(dep).requires_grad_(True)
+    v1 = de.ops.smoothness(d1, T(tgt))
+    v1.backward()
+    d2 = T(dep).requires_grad_(True)
+    v2 = de.ops.smoothness(d2, T(stacked))
+    v2.backward()
+    assert abs(float(v1) - float(v2)) <= 1e-6 * abs(float(v2))
+    assert rel_to_max(N(d1.grad), N(d2.grad)) < 1e-6 or np.abs(N(d2.grad)).max() == 0
+    if H > 1 and W > 1:
+        assert abs(float(v1) - want) < 1e-4 * abs(want)
+        assert rel_to_max(N(d1.grad), g_want) < 1e-4
+
+
 def test_train_step_loss_matches_per_sample_composition(de):
     """fused.train_step_loss (train.py:83-89 for B targets at once) == the per-sample composition the reference
     writes: sum_b [ mean(out/exp(idt+1e-6)) + 0.02 * regularization_term(depth_b/80, target x S) ], values and
