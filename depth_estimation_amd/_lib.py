@@ -52,7 +52,7 @@ _SIGNATURES = {
     "ds_smooth_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp, _sz, _fp]),
     "ds_smooth_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp]),
     "ds_smooth_batch_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _sz, _fp]),
-    "ds_smooth_batch_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp]),
+    "ds_smooth_batch_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp]),
     "ds_ingest_u8": (_i, [_fp, _i, _i, _i, _fp, _fp]),
     "ds_metrics_workspace_bytes": (_sz, [_i, _i, _i]),
     "ds_depth_metrics": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _sz, _fp]),
@@ -86,7 +86,9 @@ def check(rc: int, what: str) -> None:
 
 
 def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current stream on the current device (torch.cuda.current_stream() builds a Python object
+    per call, ~12 us each: four of them were a tenth of a small loss step)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -106,6 +108,10 @@ def same_device(*ts: torch.Tensor) -> None:
     for t in ts[1:]:
         if t.device != d:
             raise RuntimeError(f"expected all tensors on {d}, got {t.device}")
+    if d.index is not None and d.index != torch._C._cuda_getDevice():
+        # the kernels are launched on the current device's stream
+        raise RuntimeError(f"tensors are on {d} but the current device is cuda:{torch._C._cuda_getDevice()}; "
+                           "call torch.cuda.set_device first")
 
 
 def ptr(t) -> int:
@@ -113,13 +119,14 @@ def ptr(t) -> int:
 
 
 class Workspace:
-    """Per-device scratch buffer reused across calls (kernels never allocate)."""
+    """Scratch buffer per (device, stream), reused across calls (kernels never allocate); calls on one stream are
+    ordered, calls on different streams must not share partial sums."""
 
     def __init__(self):
         self._buf = {}
 
     def get(self, nbytes: int, device: torch.device) -> torch.Tensor:
-        key = (device.type, device.index)
+        key = (device.index, stream())
         buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)

@@ -281,7 +281,7 @@ __device__ __forceinline__ float grad1d_adjoint(float qm, float q0, float qp, in
 __global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(const float* __restrict__ depths,
                                                               const float* __restrict__ targets,
                                                               const float* __restrict__ g_value, int N, int S, int C, int H,
-                                                              int W, float* __restrict__ g_depths) {
+                                                              int W, int accumulate, float* __restrict__ g_depths) {
     const int n = blockIdx.y, HW = H * W;
     const int p = blockIdx.x * kThreads + threadIdx.x;
     if (p >= HW) return;
@@ -295,7 +295,8 @@ __global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(const float* __res
     if (x <= W - 2) smooth_q(D, T, C, H, W, y, x + 1, g, qxp, dummy);
     if (y >= 1) smooth_q(D, T, C, H, W, y - 1, x, g, dummy, qym);
     if (y <= H - 2) smooth_q(D, T, C, H, W, y + 1, x, g, dummy, qyp);
-    g_depths[(size_t)n * HW + p] = grad1d_adjoint(qxm, qx0, qxp, x, W) + grad1d_adjoint(qym, qy0, qyp, y, H);
+    const float v = grad1d_adjoint(qxm, qx0, qxp, x, W) + grad1d_adjoint(qym, qy0, qyp, y, H);
+    g_depths[(size_t)n * HW + p] = accumulate ? g_depths[(size_t)n * HW + p] + v : v;
 }
 
 // ---- tiled smoothness for C == 3 ------------------------------------------------------------------
@@ -378,7 +379,8 @@ template <int S>
 __global__ __launch_bounds__(kThreads) void smooth_tiled_bwd_kernel(const float* __restrict__ depths,
                                                                     const float* __restrict__ targets,
                                                                     const float* __restrict__ g_value, float inv_count,
-                                                                    SmoothGeom G, float* __restrict__ g_depths) {
+                                                                    SmoothGeom G, int accumulate,
+                                                                    float* __restrict__ g_depths) {
     const int t = blockIdx.y, HW = G.H * G.W;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int bx = blockIdx.x % G.nbx, by = blockIdx.x / G.nbx;
@@ -433,7 +435,9 @@ __global__ __launch_bounds__(kThreads) void smooth_tiled_bwd_kernel(const float*
             if (emit && store) {
                 const float up = y >= 1 ? qy[s][0] : -qy[s][1];
                 const float down = y <= G.H - 2 ? qyn : -qy[s][1];
-                O[s * HW + y * G.W + x] = gx[s] + (up - down);
+                float* o = O + s * HW + y * G.W + x;
+                const float v = gx[s] + (up - down);
+                *o = accumulate ? *o + v : v;
             }
             qy[s][0] = qy[s][1];
             qy[s][1] = qyn;
@@ -818,7 +822,7 @@ int ds_smooth_batch_fwd(const float* depths, const float* targets, int B, int S,
 }
 
 int ds_smooth_batch_bwd(const float* depths, const float* targets, const float* g_value, int B, int S, int C, int H, int W,
-                        float* g_depths, void* stream) {
+                        int accumulate, float* g_depths, void* stream) {
     if (!depths || !targets || !g_value || !g_depths || B <= 0 || S <= 0 || (long long)B * S > 65535 ||
         bad_img(B * S, C, H, W))
         return DS_ERR_INVALID_ARG;
@@ -826,7 +830,7 @@ int ds_smooth_batch_bwd(const float* depths, const float* targets, const float* 
     hipStream_t st = (hipStream_t)stream;
     if (C != 3) {
         hipLaunchKernelGGL(smooth_bwd_kernel, dim3(pix_blocks(H * W), N), dim3(kThreads), 0, st, depths, targets, g_value, N, S,
-                           C, H, W, g_depths);
+                           C, H, W, accumulate, g_depths);
         DS_CHECK_LAUNCH();
         return DS_OK;
     }
@@ -835,10 +839,10 @@ int ds_smooth_batch_bwd(const float* depths, const float* targets, const float* 
         const SmoothGeom G{H, W, (W + 61) / 62, S, s0, std::min(kSmoothMaxS, S - s0)};
         dim3 grid(smooth_bwd_blocks(H, W), B), blk(kThreads);
         switch (G.sn) {
-            case 1: hipLaunchKernelGGL(smooth_tiled_bwd_kernel<1>, grid, blk, 0, st, depths, targets, g_value, inv_count, G, g_depths); break;
-            case 2: hipLaunchKernelGGL(smooth_tiled_bwd_kernel<2>, grid, blk, 0, st, depths, targets, g_value, inv_count, G, g_depths); break;
-            case 3: hipLaunchKernelGGL(smooth_tiled_bwd_kernel<3>, grid, blk, 0, st, depths, targets, g_value, inv_count, G, g_depths); break;
-            default: hipLaunchKernelGGL(smooth_tiled_bwd_kernel<4>, grid, blk, 0, st, depths, targets, g_value, inv_count, G, g_depths); break;
+            case 1: hipLaunchKernelGGL(smooth_tiled_bwd_kernel<1>, grid, blk, 0, st, depths, targets, g_value, inv_count, G, accumulate, g_depths); break;
+            case 2: hipLaunchKernelGGL(smooth_tiled_bwd_kernel<2>, grid, blk, 0, st, depths, targets, g_value, inv_count, G, accumulate, g_depths); break;
+            case 3: hipLaunchKernelGGL(smooth_tiled_bwd_kernel<3>, grid, blk, 0, st, depths, targets, g_value, inv_count, G, accumulate, g_depths); break;
+            default: hipLaunchKernelGGL(smooth_tiled_bwd_kernel<4>, grid, blk, 0, st, depths, targets, g_value, inv_count, G, accumulate, g_depths); break;
         }
         DS_CHECK_LAUNCH();
     }
@@ -852,7 +856,7 @@ int ds_smooth_fwd(const float* depths, const float* targets, int N, int C, int H
 
 int ds_smooth_bwd(const float* depths, const float* targets, const float* g_value, int N, int C, int H, int W,
                   float* g_depths, void* stream) {
-    return ds_smooth_batch_bwd(depths, targets, g_value, N, 1, C, H, W, g_depths, stream);
+    return ds_smooth_batch_bwd(depths, targets, g_value, N, 1, C, H, W, 0, g_depths, stream);
 }
 
 size_t ds_metrics_workspace_bytes(int B, int H, int W) {

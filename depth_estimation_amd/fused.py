@@ -37,17 +37,18 @@ def fused_reprojection_loss(src: torch.Tensor, target: torch.Tensor, depth: torc
 
 def train_step_loss(src, target, depth, pose, K, Kinv, max_depth: float = 80.0, smooth_weight: float = 0.02):
     """Summed training loss of train.py:83-89 over the B targets: sum_b [ mean(out/exp(idt+1e-6)) +
-    0.02 * regularization_term(depth_b/80, target_b stacked S times) ]."""
-    b, s = src.shape[:2]
-    r = fused_reprojection_loss(src, target, depth, pose, K, Kinv)
-    loss = r["loss"].sum()
-    h, w = target.shape[-2:]
-    # the reference's regularization mean is per sample (N = S maps of H*W pixels each, train.py:83) and the samples
-    # are summed (train.py:89): every sample has the same pixel count, so the sum of the per-sample means is
-    # B x the mean over all B*S maps -- one launch instead of B, and the S maps of a target share its edge weights
-    loss = loss + (smooth_weight * b) * ops.smoothness((depth / max_depth).reshape(b * s, 1, h, w), target)
-    r["total"] = loss
-    return r
+    0.02 * regularization_term(depth_b/80, target_b stacked S times) ], as ONE autograd node (ops.train_step).
+
+    The reference's regularization mean is per sample (N = S maps of H*W pixels each, train.py:83) and the samples are
+    summed (train.py:89): every sample has the same pixel count, so the sum of the per-sample means is B x the mean over
+    all B*S maps -- one launch instead of B, and the S maps of a target share its edge weights.  The term is linear in
+    the depth scale, regularization_term(d / 80) = regularization_term(d) / 80, which saves an elementwise pass over the
+    depth maps and its backward."""
+    b = src.shape[0]
+    total, sums, reg, warped, out_loss, idt_loss, aux = ops.train_step(K, Kinv, pose, depth, src.detach(), target.detach(),
+                                                                       smooth_weight * b / max_depth)
+    return dict(total=total, loss=sums[:, 0], log=sums[:, 1], reg=reg, warped=warped, out_loss=out_loss,
+                idt_loss=idt_loss, aux=aux)
 
 
 def candidate_depths(src, target, pose, K_cost, Kinv_cost, depths, cost_size, sid: bool = True) -> torch.Tensor:

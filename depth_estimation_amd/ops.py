@@ -278,10 +278,13 @@ class _FusedLoss(torch.autograd.Function):
                 "ds_fused_loss_fwd")
         ctx.save_for_backward(warped, target, idt, aux)
         ctx.mark_non_differentiable(out, idt, aux)
+        ctx.set_materialize_grads(False)  # no zero-filled (B,H,W) gradients for the three maps
         return sums, out, idt, aux
 
     @staticmethod
     def backward(ctx, g_sums, _g_out, _g_idt, _g_aux):
+        if g_sums is None:
+            return None, None, None
         warped, target, idt, aux = ctx.saved_tensors
         b, s, c, h, w = warped.shape
         # only sums[:,0] (the auto-masked mean, train.py:88) carries gradient; sums[:,1] is a log value
@@ -328,7 +331,7 @@ class _Smooth(torch.autograd.Function):
         s = depths.shape[0] // b
         g = L.dev_f32(g.reshape(1), "grad")
         gd = torch.empty_like(depths)
-        L.check(L.lib().ds_smooth_batch_bwd(depths.data_ptr(), targets.data_ptr(), g.data_ptr(), b, s, c, h, w,
+        L.check(L.lib().ds_smooth_batch_bwd(depths.data_ptr(), targets.data_ptr(), g.data_ptr(), b, s, c, h, w, 0,
                                             gd.data_ptr(), L.stream()), "ds_smooth_batch_bwd")
         return gd, None
 
@@ -337,6 +340,82 @@ def smoothness(depths, targets) -> torch.Tensor:
     """metrics.regularization_term (metrics.py:75-97): depths (N,1,H,W), targets (N,C,H,W) -> scalar.  With targets
     (B,C,H,W) and N = B*S the S maps b*S..b*S+S-1 share target b (the stack of train.py:80 left implicit)."""
     return _Smooth.apply(depths, targets)
+
+
+# ----------------------------------------------------------------------------------------------------
+# the whole loss step as one autograd node (train.py:72-89 for B targets)
+# ----------------------------------------------------------------------------------------------------
+class _TrainStep(torch.autograd.Function):
+    """Five C-ABI calls forward (warp, photometric loss, smoothness) and three backward, no intermediate autograd nodes,
+    no elementwise torch kernels over image-sized tensors: the smoothness gradient is accumulated onto the photometric
+    depth gradient inside its kernel."""
+
+    @staticmethod
+    def forward(ctx, K, Kinv, pose, depth, src, target, smooth_scale):
+        depth, src, target = L.dev_f32(depth, "depth"), L.dev_f32(src, "src"), L.dev_f32(target, "target")
+        b, s, c, hs, ws = src.shape
+        h, w = target.shape[-2:]
+        n = b * s
+        ctx.pose_shape = pose.shape
+        if c != 3 or target.shape != (b, 3, h, w) or depth.numel() != n * h * w or (hs, ws) != (h, w):
+            raise RuntimeError(f"expected src (B,S,3,H,W), target (B,3,H,W), depth (B,S,1,H,W); got {tuple(src.shape)}, "
+                               f"{tuple(target.shape)}, {tuple(depth.shape)}")
+        K, Kinv, pose = _chk_cam(K, Kinv, pose.reshape(n, 3, 4), n)
+        L.same_device(depth, src, target, K, Kinv, pose)
+        dev, lib, st = src.device, L.lib(), L.stream()
+        f32 = dict(dtype=torch.float32, device=dev)
+        warped = torch.empty(b, s, 3, h, w, **f32)
+        L.check(lib.ds_warp_fwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(), n, 3, h, w,
+                                h, w, warped.data_ptr(), st), "ds_warp_fwd")
+        out, idt = torch.empty(b, h, w, **f32), torch.empty(b, h, w, **f32)
+        aux = torch.empty(b, h, w, dtype=torch.uint8, device=dev)
+        sums, reg = torch.empty(b, 2, **f32), torch.empty(1, **f32)
+        nb = max(lib.ds_fused_loss_workspace_bytes(b, h, w), lib.ds_smooth_workspace_bytes(n, h, w),
+                 lib.ds_warp_bwd_workspace_bytes(n, h, w))
+        wsb = L.workspace.get(nb, dev)
+        L.check(lib.ds_fused_loss_fwd(warped.data_ptr(), src.data_ptr(), target.data_ptr(), b, s, h, w, out.data_ptr(),
+                                      idt.data_ptr(), aux.data_ptr(), sums.data_ptr(), wsb.data_ptr(), nb, st),
+                "ds_fused_loss_fwd")
+        L.check(lib.ds_smooth_batch_fwd(depth.data_ptr(), target.data_ptr(), b, s, 3, h, w, reg.data_ptr(), wsb.data_ptr(), nb,
+                                        st), "ds_smooth_batch_fwd")
+        total = sums[:, 0].sum() + smooth_scale * reg[0]
+        ctx.save_for_backward(K, Kinv, pose, depth, src, target, warped, idt, aux)
+        ctx.smooth_scale, ctx.nb = smooth_scale, nb
+        ctx.mark_non_differentiable(sums, reg, warped, out, idt, aux)
+        ctx.set_materialize_grads(False)
+        return total, sums, reg, warped, out, idt, aux
+
+    @staticmethod
+    def backward(ctx, g_total, *_unused):
+        if g_total is None:
+            return (None,) * 7
+        K, Kinv, pose, depth, src, target, warped, idt, aux = ctx.saved_tensors
+        if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:
+            raise RuntimeError("train_step_loss: gradients w.r.t. the images are not implemented (use "
+                               "fused_reprojection_loss(image_grad=True))")
+        b, s, _, h, w = src.shape
+        n = b * s
+        dev, lib, st = src.device, L.lib(), L.stream()
+        g_total = L.dev_f32(g_total.reshape(1), "grad")
+        g_sums = g_total.expand(b).contiguous()
+        g_reg = g_total * ctx.smooth_scale
+        gw = torch.empty_like(warped)
+        L.check(lib.ds_fused_loss_bwd(warped.data_ptr(), target.data_ptr(), idt.data_ptr(), aux.data_ptr(), g_sums.data_ptr(),
+                                      b, s, h, w, gw.data_ptr(), st), "ds_fused_loss_bwd")
+        gd, gp = torch.empty_like(depth), torch.empty_like(pose)
+        wsb = L.workspace.get(ctx.nb, dev)
+        L.check(lib.ds_warp_bwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
+                                gw.data_ptr(), n, 3, h, w, h, w, gd.data_ptr(), gp.data_ptr(), 0, wsb.data_ptr(), ctx.nb, st),
+                "ds_warp_bwd")
+        L.check(lib.ds_smooth_batch_bwd(depth.data_ptr(), target.data_ptr(), g_reg.data_ptr(), b, s, 3, h, w, 1,
+                                        gd.data_ptr(), st), "ds_smooth_batch_bwd")
+        return None, None, gp.reshape(ctx.pose_shape), gd, None, None, None
+
+
+def train_step(K, Kinv, pose, depth, src, target, smooth_scale: float):
+    """-> (total, sums (B,2), reg (1), warped, out_loss, idt_loss, aux): total = sum_b sums[b,0] + smooth_scale *
+    regularization_term(depth maps, targets), differentiable w.r.t. depth and pose; pose (B*S,3,4) or (B,S,3,4)."""
+    return _TrainStep.apply(K, Kinv, pose, depth, src, target, float(smooth_scale))
 
 
 # ----------------------------------------------------------------------------------------------------

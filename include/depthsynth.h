@@ -150,8 +150,9 @@ int ds_smooth_bwd(const float* depths, const float* targets, const float* g_valu
  * equal-sized samples, see fused.train_step_loss).  workspace from ds_smooth_workspace_bytes(B*S, H, W). */
 int ds_smooth_batch_fwd(const float* depths, const float* targets, int B, int S, int C, int H, int W, float* value,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* accumulate != 0: g_depths += the gradient (the depth maps usually carry the photometric gradient already). */
 int ds_smooth_batch_bwd(const float* depths, const float* targets, const float* g_value, int B, int S, int C, int H, int W,
-                        float* g_depths, void* stream);
+                        int accumulate, float* g_depths, void* stream);
 
 /* metrics.rmse / rmsle / abs_rel / sq_rel (metrics.py:100-153; test.py:78-81) in ONE pass over
  * pred, gt (B,1,H,W): out (8) fp32 = rmse, rmsle, abs_rel, sq_rel, delta<1.25, <1.25^2, <1.25^3 (not in

@@ -372,27 +372,33 @@ def test_smoothness_batch_forms(de, oracle, B, S, C, H, W):
 
 
 def test_train_step_loss_matches_per_sample_composition(de):
-    """fused.train_step_loss (train.py:83-89 for B targets at once) == the per-sample composition the reference
-    writes: sum_b [ mean(out/exp(idt+1e-6)) + 0.02 * regularization_term(depth_b/80, target x S) ], values and
-    gradients (1e-4 relative)."""
+    """fused.train_step_loss (train.py:83-89 for B targets at once, one autograd node) == the per-sample composition the
+    reference writes: sum_b [ mean(out/exp(idt+1e-6)) + 0.02 * regularization_term(depth_b/80, target x S) ], values,
+    depth and pose-vector gradients (1e-4 relative), also under a non-unit upstream gradient."""
     g = torch.Generator().manual_seed(7)
     B, S, H, W = 3, 2, 40, 72
     src = torch.rand(B, S, 3, H, W, generator=g).to(DEV)
     tgt = torch.rand(B, 3, H, W, generator=g).to(DEV)
     depth = (1 + 79 * torch.rand(B, S, 1, H, W, generator=g)).to(DEV)
-    pose = de.ops.pose_from_vec((0.01 * torch.randn(B * S, 6, generator=g)).to(DEV)).reshape(B, S, 3, 4)
+    vec = (0.01 * torch.randn(B * S, 6, generator=g)).to(DEV)
     K, Kinv = [t.to(DEV) for t in de.fused.intrinsics(W, H)]
-    d1 = depth.clone().requires_grad_(True)
-    r = de.fused.train_step_loss(src, tgt, d1, pose, K, Kinv)
-    r["total"].backward()
-    d2 = depth.clone().requires_grad_(True)
+    d1, v1 = depth.clone().requires_grad_(True), vec.clone().requires_grad_(True)
+    r = de.fused.train_step_loss(src, tgt, d1, de.ops.pose_from_vec(v1).reshape(B, S, 3, 4), K, Kinv)
+    (r["total"] * 1.7).backward()
+    d2, v2 = depth.clone().requires_grad_(True), vec.clone().requires_grad_(True)
+    pose2 = de.ops.pose_from_vec(v2).reshape(B, S, 3, 4)
     total = 0.0
     for b in range(B):
-        rb = de.fused.fused_reprojection_loss(src[b:b + 1], tgt[b:b + 1], d2[b:b + 1], pose[b:b + 1], K, Kinv)
+        rb = de.fused.fused_reprojection_loss(src[b:b + 1], tgt[b:b + 1], d2[b:b + 1], pose2[b:b + 1], K, Kinv)
         total = total + rb["loss"].sum() + 0.02 * de.metrics.regularization_term(d2[b] / 80.0, torch.stack([tgt[b]] * S))
-    total.backward()
+    (total * 1.7).backward()
     assert abs(float(r["total"]) - float(total)) < 1e-5 * abs(float(total))
     assert rel_to_max(N(d1.grad), N(d2.grad)) < 1e-4
+    assert rel_to_max(N(v1.grad), N(v2.grad)) < 1e-4
+    # the extras are those of fused_reprojection_loss
+    rb = de.fused.fused_reprojection_loss(src, tgt, depth, pose2.detach(), K, Kinv)
+    assert np.array_equal(N(r["loss"]), N(rb["loss"])) and np.array_equal(N(r["aux"]), N(rb["aux"]))
+    assert np.array_equal(N(r["out_loss"]), N(rb["out_loss"])) and np.array_equal(N(r["warped"]), N(rb["warped"]))
 
 
 def test_ingest_u8_matches_to_tensor(de):
