@@ -532,43 +532,51 @@ __global__ __launch_bounds__(kThreads) void metrics_kernel(const float* __restri
 }
 
 // partials (B, nblk, 8) -> out (8): per-image finalisation then mean over B (metrics.py:111,125,139,153)
-// One workgroup of kFinWaves waves: wave w takes the images w, w + kFinWaves, ...; its lanes split the image's block
-// partials (two 16-byte loads each), sums in double, fixed order throughout (deterministic).
-constexpr int kFinWaves = 16;
-
-__global__ __launch_bounds__(kFinWaves * 64) void metrics_finalize_kernel(const float* __restrict__ partials, int B, int nblk,
-                                                                          double inv_hw, float* __restrict__ out) {
-    __shared__ double lds[kFinWaves][8];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int b = wave; b < B; b += kFinWaves) {
-        double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int j = lane; j < nblk; j += 64) {
-            const float4* q = reinterpret_cast<const float4*>(partials + ((size_t)b * nblk + j) * 8);
-            const float4 lo = q[0], hi = q[1];
-            s[0] += (double)lo.x; s[1] += (double)lo.y; s[2] += (double)lo.z; s[3] += (double)lo.w;
-            s[4] += (double)hi.x; s[5] += (double)hi.y; s[6] += (double)hi.z; s[7] += (double)hi.w;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_xor(s[k], o, 64);
-        }
-        acc[0] += sqrt(s[0] * inv_hw);
-        acc[1] += sqrt(s[1] * inv_hw);
-#pragma unroll
-        for (int k = 2; k < 7; ++k) acc[k] += s[k] * inv_hw;
-        acc[7] += s[7];
+// Two short kernels, fixed summation order (deterministic): one workgroup per image sums the image's block partials in
+// double (every thread one or a few independent 32-byte loads) and forms the image's terms; one wave sums over the images.
+__global__ __launch_bounds__(kThreads) void metrics_image_kernel(const float* __restrict__ partials, int nblk, double inv_hw,
+                                                                 double* __restrict__ per_image) {
+    __shared__ double lds[kThreads / 64][8];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+    for (int j = threadIdx.x; j < nblk; j += kThreads) {
+        const float4* q = reinterpret_cast<const float4*>(partials + ((size_t)b * nblk + j) * 8);
+        const float4 lo = q[0], hi = q[1];
+        s[0] += (double)lo.x; s[1] += (double)lo.y; s[2] += (double)lo.z; s[3] += (double)lo.w;
+        s[4] += (double)hi.x; s[5] += (double)hi.y; s[6] += (double)hi.z; s[7] += (double)hi.w;
     }
-    if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) lds[wave][k] = acc[k];
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_xor(s[k], o, 64);
+        if (lane == 0) lds[wave][k] = s[k];
     }
     __syncthreads();
     if (threadIdx.x < 8) {
+        const int k = threadIdx.x;
         double t = 0.0;
-        for (int w = 0; w < kFinWaves; ++w) t += lds[w][threadIdx.x];
-        out[threadIdx.x] = threadIdx.x < 7 ? (float)(t / (double)B) : (float)t;
+        for (int w = 0; w < kThreads / 64; ++w) t += lds[w][k];
+        per_image[(size_t)b * 8 + k] = k < 2 ? sqrt(t * inv_hw) : (k < 7 ? t * inv_hw : t);
+    }
+}
+
+__global__ __launch_bounds__(64) void metrics_finalize_kernel(const double* __restrict__ per_image, int B,
+                                                              float* __restrict__ out) {
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < B; b += 64) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += per_image[(size_t)b * 8 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) out[k] = (float)(acc[k] / (double)B);
+        out[7] = (float)acc[7];
     }
 }
 
@@ -861,7 +869,8 @@ int ds_smooth_bwd(const float* depths, const float* targets, const float* g_valu
 
 size_t ds_metrics_workspace_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)B * metric_blocks(H * W) * 8 * sizeof(float);
+    // block partials (8 floats each), then 8 doubles per image
+    return (size_t)B * metric_blocks(H * W) * 8 * sizeof(float) + (size_t)B * 8 * sizeof(double);
 }
 
 int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, float* out, void* workspace,
@@ -871,11 +880,14 @@ int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, fl
         return DS_ERR_WORKSPACE;
     const int nb = metric_blocks(H * W);
     const int vec = ((H * W) & 3) == 0 && (((uintptr_t)pred | (uintptr_t)gt) & 15) == 0;
-    hipLaunchKernelGGL(metrics_kernel, dim3(nb, B), dim3(kThreads), 0, (hipStream_t)stream, pred, gt, H * W, vec,
-                       (float*)workspace);
+    float* partials = (float*)workspace;
+    double* per_image = (double*)(partials + (size_t)B * nb * 8);  // 32 * B * nb bytes in: 8-byte aligned
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(metrics_kernel, dim3(nb, B), dim3(kThreads), 0, st, pred, gt, H * W, vec, partials);
     DS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(kFinWaves * 64), 0, (hipStream_t)stream, (const float*)workspace, B, nb,
-                       1.0 / ((double)H * W), out);
+    hipLaunchKernelGGL(metrics_image_kernel, dim3(B), dim3(kThreads), 0, st, partials, nb, 1.0 / ((double)H * W), per_image);
+    DS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(64), 0, st, per_image, B, out);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }
