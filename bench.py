@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="sub-batches per step, each on its own HIP stream: the memory-bound warp kernels of one overlap "
                          "the VALU-bound loss kernels of the other (1 = whole batch on one stream)")
+    ap.add_argument("--join", action="store_true",
+                    help="join the side streams into the current stream after every step (a training loop's optimizer step "
+                         "needs all gradients): the sub-batches then overlap within a step only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -209,11 +212,18 @@ def main():
         for sc in scales:
             if sc.g_src is not None:
                 sc.g_src.zero_()
+        if args.join:
+            cur = torch.cuda.current_stream()
+            for ss in side_streams:
+                ss.wait_stream(cur)
         for name in scales[0].names:
             for j, sc in enumerate(scales):
                 rc = sc.calls[name](side_streams[j].cuda_stream)
                 if rc != 0:
                     sc.L.check(rc, name)
+        if args.join:
+            for ss in side_streams:
+                cur.wait_stream(ss)
 
     graph = None
     if args.graph:
@@ -286,6 +296,22 @@ def main():
     if parts > 1:
         del scales
         scales = build_problem(de, wl, dev, rank, image_grad, 1)
+    # the same K steps with the whole batch on the current stream (no overlap between sub-batches): what a caller sees that
+    # orders every step after the previous one; reported beside `value`
+    sequential = None
+    if parts > 1:
+        for _ in range(args.warmup):
+            for sc in scales:
+                sc.step(st)
+        torch.cuda.synchronize()
+        s0 = time.perf_counter()
+        for _ in range(args.steps):
+            for sc in scales:
+                sc.step(st)
+        torch.cuda.synchronize()
+        sdt = time.perf_counter() - s0
+        sequential = {"value": round(warped_px_rank * args.steps / sdt / 1e9, 4), "unit": "Gpix/s (this rank)",
+                      "ms_per_step": round(sdt / args.steps * 1e3, 5), "launch": "whole batch on one stream"}
     sc0 = scales[0]
     ev = {n: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
           for n in names}
@@ -320,7 +346,7 @@ def main():
             "config": {"workload": args.workload, "targets_per_gpu": wl["B"], "sources_per_target": wl["S"],
                        "height": wl["H"], "width": wl["W"], "scales": wl["scales"], "image_grad": bool(image_grad),
                        "metrics_reduce": bool(wl.get("metrics", False)),
-                       "launch": ("hipgraph" if args.graph else "eager") + ("" if parts == 1 else f", {parts} sub-batches on {parts} streams"),
+                       "launch": ("hipgraph" if args.graph else "eager") + ("" if parts == 1 else f", {parts} sub-batches on {parts} streams" + (", joined every step" if args.join else "")),
                        "parallelism": f"batch-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -329,6 +355,8 @@ def main():
             "step_alg_GBps": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
             "step_frac_of_hbm_peak": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
         }
+        if sequential is not None:
+            line["one_stream"] = sequential
         if cold is not None:
             line["cold_cache"] = cold
         if not args.no_cpu:

@@ -9,7 +9,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef DS_OK
 #define DS_OK 0
+#endif
 #define DS_ERR_INVALID_ARG (-1)
 #define DS_ERR_UNSUPPORTED (-2)
 #define DS_ERR_WORKSPACE (-3)

@@ -346,9 +346,9 @@ def smoothness(depths, targets) -> torch.Tensor:
 # the whole loss step as one autograd node (train.py:72-89 for B targets)
 # ----------------------------------------------------------------------------------------------------
 class _TrainStep(torch.autograd.Function):
-    """Five C-ABI calls forward (warp, photometric loss, smoothness) and three backward, no intermediate autograd nodes,
-    no elementwise torch kernels over image-sized tensors: the smoothness gradient is accumulated onto the photometric
-    depth gradient inside its kernel."""
+    """Two C-ABI calls forward (warp + photometric loss, smoothness) and two backward, no intermediate
+    autograd nodes, no elementwise torch kernels over image-sized tensors: the smoothness gradient is accumulated onto
+    the photometric depth gradient inside its kernel."""
 
     @staticmethod
     def forward(ctx, K, Kinv, pose, depth, src, target, smooth_scale):
@@ -364,18 +364,16 @@ class _TrainStep(torch.autograd.Function):
         L.same_device(depth, src, target, K, Kinv, pose)
         dev, lib, st = src.device, L.lib(), L.stream()
         f32 = dict(dtype=torch.float32, device=dev)
+        nb = max(lib.ds_loss_step_workspace_bytes(b, s, h, w), lib.ds_smooth_workspace_bytes(n, h, w))
+        wsb = L.workspace.get(nb, dev)
         warped = torch.empty(b, s, 3, h, w, **f32)
-        L.check(lib.ds_warp_fwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(), n, 3, h, w,
-                                h, w, warped.data_ptr(), st), "ds_warp_fwd")
         out, idt = torch.empty(b, h, w, **f32), torch.empty(b, h, w, **f32)
         aux = torch.empty(b, h, w, dtype=torch.uint8, device=dev)
         sums, reg = torch.empty(b, 2, **f32), torch.empty(1, **f32)
-        nb = max(lib.ds_fused_loss_workspace_bytes(b, h, w), lib.ds_smooth_workspace_bytes(n, h, w),
-                 lib.ds_warp_bwd_workspace_bytes(n, h, w))
-        wsb = L.workspace.get(nb, dev)
-        L.check(lib.ds_fused_loss_fwd(warped.data_ptr(), src.data_ptr(), target.data_ptr(), b, s, h, w, out.data_ptr(),
-                                      idt.data_ptr(), aux.data_ptr(), sums.data_ptr(), wsb.data_ptr(), nb, st),
-                "ds_fused_loss_fwd")
+        L.check(lib.ds_loss_step_fwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
+                                     target.data_ptr(), b, s, h, w, warped.data_ptr(), out.data_ptr(), idt.data_ptr(),
+                                     aux.data_ptr(), sums.data_ptr(), wsb.data_ptr(), nb, st),
+                "ds_loss_step_fwd")
         L.check(lib.ds_smooth_batch_fwd(depth.data_ptr(), target.data_ptr(), b, s, 3, h, w, reg.data_ptr(), wsb.data_ptr(), nb,
                                         st), "ds_smooth_batch_fwd")
         total = sums[:, 0].sum() + smooth_scale * reg[0]
@@ -394,19 +392,17 @@ class _TrainStep(torch.autograd.Function):
             raise RuntimeError("train_step_loss: gradients w.r.t. the images are not implemented (use "
                                "fused_reprojection_loss(image_grad=True))")
         b, s, _, h, w = src.shape
-        n = b * s
         dev, lib, st = src.device, L.lib(), L.stream()
         g_total = L.dev_f32(g_total.reshape(1), "grad")
         g_sums = g_total.expand(b).contiguous()
         g_reg = g_total * ctx.smooth_scale
         gw = torch.empty_like(warped)
-        L.check(lib.ds_fused_loss_bwd(warped.data_ptr(), target.data_ptr(), idt.data_ptr(), aux.data_ptr(), g_sums.data_ptr(),
-                                      b, s, h, w, gw.data_ptr(), st), "ds_fused_loss_bwd")
         gd, gp = torch.empty_like(depth), torch.empty_like(pose)
         wsb = L.workspace.get(ctx.nb, dev)
-        L.check(lib.ds_warp_bwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
-                                gw.data_ptr(), n, 3, h, w, h, w, gd.data_ptr(), gp.data_ptr(), 0, wsb.data_ptr(), ctx.nb, st),
-                "ds_warp_bwd")
+        L.check(lib.ds_loss_step_bwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
+                                     target.data_ptr(), warped.data_ptr(), idt.data_ptr(), aux.data_ptr(), g_sums.data_ptr(),
+                                     b, s, h, w, gw.data_ptr(), gd.data_ptr(), gp.data_ptr(), wsb.data_ptr(), ctx.nb, st),
+                "ds_loss_step_bwd")
         L.check(lib.ds_smooth_batch_bwd(depth.data_ptr(), target.data_ptr(), g_reg.data_ptr(), b, s, 3, h, w, 1,
                                         gd.data_ptr(), st), "ds_smooth_batch_bwd")
         return None, None, gp.reshape(ctx.pose_shape), gd, None, None, None

@@ -26,6 +26,7 @@
 extern "C" {
 #endif
 
+#define DS_OK 0
 #define DS_ERR_INVALID_ARG (-1)
 #define DS_ERR_UNSUPPORTED (-2)
 #define DS_ERR_WORKSPACE   (-3)
@@ -136,6 +137,19 @@ int ds_fused_loss_fwd(const float* warped, const float* src, const float* target
 /* autograd of sums[b][0] w.r.t. warped: g_sums (B) = d(loss)/d(sums[b][0]) -> g_warped (B,S,3,H,W). */
 int ds_fused_loss_bwd(const float* warped, const float* target, const float* idt_loss, const uint8_t* aux,
                       const float* g_sums, int B, int S, int H, int W, float* g_warped, void* stream);
+
+/* The two halves of a loss step in one call each, on the caller's stream: ds_warp_fwd + ds_fused_loss_fwd, and
+ * ds_fused_loss_bwd + ds_warp_bwd (train.py:72-88 and its autograd for B targets; source and grid sizes equal).
+ * Arguments as in the four calls; g_warped (B,S,3,H,W) is scratch for the backward.  Same launches, half the calls for a
+ * host layer that pays per call. */
+size_t ds_loss_step_workspace_bytes(int B, int S, int H, int W);
+int ds_loss_step_fwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                     const float* target, int B, int S, int H, int W, float* warped, float* out_loss, float* idt_loss,
+                     uint8_t* aux, float* sums, void* workspace, size_t workspace_bytes, void* stream);
+int ds_loss_step_bwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                     const float* target, const float* warped, const float* idt_loss, const uint8_t* aux,
+                     const float* g_sums, int B, int S, int H, int W, float* g_warped, float* g_depth, float* g_pose,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* metrics.regularization_term (metrics.py:75-97): depths (N,1,H,W), targets (N,C,H,W) -> value (1)
  * fp32 on device; workspace from ds_smooth_workspace_bytes. */

@@ -31,6 +31,26 @@ def test_library_exports_every_declared_symbol():
     assert handle.ds_warp_bwd_workspace_bytes(24, 192, 640) == 24 * 120 * 12 * 4
 
 
+def test_every_entry_point_rejects_null_arguments_on_the_host():
+    """Argument validation precedes any launch (error behaviour): every int-returning entry point called
+    with null pointers and zero sizes returns an error code instead of touching the device -- safe without a GPU."""
+    import ctypes as C
+    from depth_estimation_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libdepthsynth.so not built (run __graft_entry__.build())")
+    handle = _lib.lib()
+    checked = 0
+    for name, (restype, argtypes) in _lib._SIGNATURES.items():
+        if restype is not C.c_int or not argtypes:
+            continue
+        args = [None if a in (C.c_void_p, C.POINTER(C.c_double)) else 0 for a in argtypes]
+        rc = getattr(handle, name)(*args)
+        assert rc in (-1, -2, -3), f"{name}(nulls) returned {rc}"
+        assert handle.ds_error_string(rc)
+        checked += 1
+    assert checked >= 25
+
+
 def test_host_wrappers_refuse_cpu_tensors():
     import torch
     from depth_estimation_amd import metrics, synthesis
