@@ -244,21 +244,33 @@ __device__ __forceinline__ void block_reduce12(float (&gM)[12], float* __restric
 #endif
 constexpr int kBwdRows = DS_BWD_ROWS;  // rows per wave: the 12-float pose-gradient wave reduction is paid once per 8 pixels
 
-// Image-gradient scatter (IMG): device-scope float atomics are the slow part of the backward with g_src (4 per pixel and
-// channel, ~100 G/s on this part), so each wave first accumulates into its own LDS tile of the source plane -- the
-// footprint of its 64 x kBwdRows target pixels for a near-identity warp, origin taken from its first row -- with LDS
-// atomics, and flushes the non-zero tile elements with one coalesced global atomic each (~1.3 per pixel and channel
-// instead of 4).  Taps that fall outside the tile (large motion, source larger than the grid) go to memory directly.
-constexpr int kTileW = 72, kTileH = kBwdRows + 6, kTileN = 3 * kTileH * kTileW;
+// Image-gradient scatter (IMG).  Direct scatter = 4 device-scope float atomics per pixel and channel: 382 us against 31 us
+// for the rest of the backward at B=12, 192x640.  Collecting the taps in an LDS tile first was measured too: the LDS float
+// atomics (~20 cycles per wave instruction) then cost what the global ones did (213 us; scripts/ubench_atomic.hip for the
+// global rates: 324 G lane-operations/s coalesced and aligned).  What is done instead needs neither: for a smooth warp the
+// taps of the 64 pixels of a wave row fall into a window of three source rows x 66 columns that moves down one row per
+// pixel row, so
+//   * lane x owns source column x + cb of the window; the taps of lanes x-1, x, x+1 that fall into that column are
+//     combined in registers (two lane shuffles per value), three running sums per channel (rows r0, r0+1, r0+2);
+//   * when the window moves on, the finished row r0 goes to memory with ONE coalesced atomic per texel and channel
+//     (atomic because the windows of neighbouring waves overlap at their edges); about 1.25 atomics per pixel and
+//     channel instead of 4, all of them full aligned lines;
+//   * pixels whose taps do not fit the window (a near pixel among far ones: its disparity differs by more than a texel)
+//     are scattered directly, lane by lane, with four atomics per channel; if more than a few lanes of a row misfit
+//     (strong minification, source larger than the grid) the whole row is.  The result never depends on the path taken.
+// B=12, 192x640, image gradient on: 382 us direct, 213 us LDS tile, 149 us this way with bench.py's random per-pixel
+// depth (about 5 % misfits), 91 us with a smooth depth map; 34 us without the image gradient (scripts/img_grad_bench.py).
+struct ImgWindow {
+    float a[3][3];   // [channel][window row]
+    float e[3][3];   // the same for the window's outer columns x0+cb-1 (held by lane 0) and x63+cb+1 (lane 63)
+    int r0, cb;      // source row of window row 0; lane x owns source column x + cb
+    bool live;
+};
 
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
     return v;
-}
-
-__device__ __forceinline__ void lds_add(float* p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 template <int C, bool IMG = false>
@@ -270,19 +282,10 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
                                                             float* __restrict__ g_depth, float* __restrict__ g_src,
                                                             float* __restrict__ partials) {
     __shared__ float lds[kThreads / 64][12];
-    __shared__ __attribute__((aligned(16))) float tiles[IMG ? kThreads / 64 : 1][IMG ? kTileN : 4];
     const int n = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int bx = blockIdx.x % G.nbx, by = blockIdx.x / G.nbx;
     const int yb = (by * (kThreads / 64) + wave) * kBwdRows;
-    float* const tile = tiles[IMG ? wave : 0];
-    int ox = 0, oy = 0;  // tile origin in the source plane (wave-uniform)
-    if (IMG) {
-        static_assert(kTileN % 4 == 0, "the tile is cleared in float4 units");
-        for (int e = lane * 4; e < kTileN; e += 64 * 4) *reinterpret_cast<float4*>(tile + e) = make_float4(0.f, 0.f, 0.f, 0.f);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
     const int x = bx * 64 + lane, xc = min(x, G.W - 1);
     const int Cc = C > 0 ? C : Cdyn;
     const unsigned HW = (unsigned)(G.H * G.W), HsWs = (unsigned)(G.Hs * G.Ws);
@@ -298,6 +301,34 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
     for (int i = 0; i < 12; ++i) gM[i] = 0.f;
     // un-normalise * normalise factors of the grid gradient (grid_sampler backward, then synthesis.py:50-51)
     const float sx = (G.w1 * 0.5f) * (2.0f * G.rw1), sy = (G.h1 * 0.5f) * (2.0f * G.rh1);
+    ImgWindow win;
+    win.live = false;
+    win.r0 = win.cb = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        win.a[c][0] = win.a[c][1] = win.a[c][2] = win.e[c][0] = win.e[c][1] = win.e[c][2] = 0.f;
+    // finished window rows go to memory: one coalesced atomic per texel and channel, one more for the two outer columns
+    auto emit_row = [&](int slot) {
+        const int r = win.r0 + slot, col = x + win.cb;
+        if (r < 0 || r >= G.Hs) return;  // uniform
+        float* q = g_src + (size_t)n * 3 * HsWs + (size_t)r * G.Ws;
+        if (col >= 0 && col < G.Ws) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (win.a[c][slot] != 0.0f) atomicAdd(q + (size_t)c * HsWs + col, win.a[c][slot]);
+        }
+        if (lane == 0 || lane == 63) {
+            const int ecol = col + (lane == 0 ? -1 : 1);  // inside the image whenever the sum is not zero
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (win.e[c][slot] != 0.0f) atomicAdd(q + (size_t)c * HsWs + ecol, win.e[c][slot]);
+        }
+    };
+    auto clear_window = [&]() {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            win.a[c][0] = win.a[c][1] = win.a[c][2] = win.e[c][0] = win.e[c][1] = win.e[c][2] = 0.f;
+    };
 #pragma unroll 2
     for (int i = 0; i < kBwdRows; ++i) {
         const int y = yb + i;
@@ -330,28 +361,103 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
             for (int c = 0; c < Cc; ++c) channel(c, buf_load_f32(gp, xb, c * HW + ro));
         }
         if (IMG) {
-            if (i == 0) {
-                ox = max(wave_min_i(t.xl) - 3, 0);
-                oy = max(wave_min_i(t.y0) - 2, 0);
-            }
-            if (x < G.W) {
-                const int tx = t.xl - ox, ty0 = t.y0 - oy, ty1 = t.y1 - oy;
-                const bool in = tx >= 0 && tx + 1 < kTileW && ty0 >= 0 && ty1 < kTileH;  // ty1 >= ty0
+            const bool valid = x < G.W;
+            const int dx = t.xl - x;
+            int rel = 0, rr = 0;
+            bool lane_ok = false;
+            // pixels of this row that do not fit the window (r0_, cb_): left texel in column x+cb-1 or x+cb, top row r0 or
+            // r0+1.  A few misfits (near pixels among far ones) are scattered directly, lane by lane; more than
+            // kMaxMisfits and the window is wrong for this row
+            constexpr int kMaxMisfits = 12;
+            auto misfits = [&](int r0_, int cb_) {
+                rel = dx - (cb_ - 1);
+                rr = t.y0 - r0_;
+                lane_ok = valid && (unsigned)rel <= 1u && (unsigned)rr <= 1u;
+                return __popcll(__ballot(valid && !lane_ok));
+            };
+            bool ok = false;
+            if (win.live) {
+                if (misfits(win.r0 + 1, win.cb) <= kMaxMisfits) {   // the usual case: the window moves down one row
+                    emit_row(0);
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
+                    for (int c = 0; c < 3; ++c) {
+                        win.a[c][0] = win.a[c][1];
+                        win.a[c][1] = win.a[c][2];
+                        win.a[c][2] = 0.f;
+                        win.e[c][0] = win.e[c][1];
+                        win.e[c][1] = win.e[c][2];
+                        win.e[c][2] = 0.f;
+                    }
+                    win.r0 += 1;
+                    ok = true;
+                } else {
+                    ok = misfits(win.r0, win.cb) <= kMaxMisfits;    // or stays
+                }
+            }
+            if (!ok) {  // a new window around the tap of the wave's first pixel (always inside the image)
+                const int d0 = __builtin_amdgcn_readfirstlane(dx), y0 = __builtin_amdgcn_readfirstlane(t.y0);
+                int best = 65, br = 0, bc = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r0_ = y0 - (k & 1), cb_ = d0 + 1 - (k >> 1);
+                    const int m = misfits(r0_, cb_);
+                    if (m < best) { best = m; br = r0_; bc = cb_; }
+                }
+                if (best <= kMaxMisfits) {
+                    if (win.live) {
+                        emit_row(0);
+                        emit_row(1);
+                        emit_row(2);
+                    }
+                    clear_window();
+                    win.r0 = br;
+                    win.cb = bc;
+                    win.live = true;
+                    misfits(br, bc);
+                    ok = true;
+                }
+            }
+            const bool direct = valid && !(ok && lane_ok);  // this pixel goes to memory with four atomics per channel
+            if (ok) {
+                // the pixel's four weights as a 3 (window rows) x 3 (owner columns x-1, x, x+1) stencil
+                const float wat = lane_ok ? t.wa_t : 0.f, wbt = lane_ok ? t.wb_t : 0.f;
+                const float wab = lane_ok ? t.wa_b : 0.f, wbb = lane_ok ? t.wb_b : 0.f;
+                const bool r1 = rel != 0, d1 = rr != 0;
+                const float ct = r1 ? wat : wbt, cm = r1 ? wab : wbb;        // own column: top, bottom
+                const float rt = r1 ? wbt : 0.f, rm = r1 ? wbb : 0.f;        // column of the right neighbour
+                const float lt = r1 ? 0.f : wat, lm = r1 ? 0.f : wab;        // column of the left neighbour
+                const float kc[3] = {d1 ? 0.f : ct, d1 ? ct : cm, d1 ? cm : 0.f};
+                const float kr[3] = {d1 ? 0.f : rt, d1 ? rt : rm, d1 ? rm : 0.f};
+                const float kl[3] = {d1 ? 0.f : lt, d1 ? lt : lm, d1 ? lm : 0.f};
+                float fromL[3], fromR[3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    fromL[s] = __shfl_up(kr[s], 1, 64);     // what lane x-1 sends to its right neighbour's column
+                    fromR[s] = __shfl_down(kl[s], 1, 64);   // what lane x+1 sends to its left neighbour's column
+                    if (lane == 0) fromL[s] = 0.f;
+                    if (lane == 63) fromR[s] = 0.f;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float gc = lane_ok ? g[c] : 0.f;
+                    const float gl = __shfl_up(gc, 1, 64), gr = __shfl_down(gc, 1, 64);
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) win.a[c][s] += fmaf(gr, fromR[s], fmaf(gl, fromL[s], gc * kc[s]));
+                    // the outer columns of the window have no owner lane: the two edge lanes keep those sums
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) win.e[c][s] = fmaf(gc, lane == 0 ? kl[s] : kr[s], win.e[c][s]);
+                }
+            }
+            if (direct) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
                     const float gc = g[c];
-                    if (in) {
-                        float* tp = tile + c * (kTileH * kTileW) + tx;
-                        lds_add(tp + ty0 * kTileW, gc * t.wa_t);
-                        lds_add(tp + ty0 * kTileW + 1, gc * t.wb_t);
-                        lds_add(tp + ty1 * kTileW, gc * t.wa_b);
-                        lds_add(tp + ty1 * kTileW + 1, gc * t.wb_b);
-                    } else if (gc != 0.0f) {
-                        float* gp = g_src + ((size_t)n * C + c) * HsWs;
-                        if (t.wa_t != 0.0f) atomicAdd(gp + (t.o_top >> 2), gc * t.wa_t);
-                        if (t.wb_t != 0.0f) atomicAdd(gp + (t.o_top >> 2) + 1, gc * t.wb_t);
-                        if (t.wa_b != 0.0f) atomicAdd(gp + (t.o_bot >> 2), gc * t.wa_b);
-                        if (t.wb_b != 0.0f) atomicAdd(gp + (t.o_bot >> 2) + 1, gc * t.wb_b);
+                    if (gc != 0.0f) {
+                        float* q = g_src + ((size_t)n * 3 + c) * HsWs;
+                        if (t.wa_t != 0.0f) atomicAdd(q + (t.o_top >> 2), gc * t.wa_t);
+                        if (t.wb_t != 0.0f) atomicAdd(q + (t.o_top >> 2) + 1, gc * t.wb_t);
+                        if (t.wa_b != 0.0f) atomicAdd(q + (t.o_bot >> 2), gc * t.wa_b);
+                        if (t.wb_b != 0.0f) atomicAdd(q + (t.o_bot >> 2) + 1, gc * t.wb_b);
                     }
                 }
             }
@@ -385,16 +491,10 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
         }
         if (x < G.W) buf_store_f32(gd, op, (unsigned)x * 4u, ro * 4u);
     }
-    if (IMG) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int e = lane; e < kTileN; e += 64) {
-            const float v = tile[e];
-            const int c = e / (kTileH * kTileW), r = e - c * (kTileH * kTileW);
-            const int ty = r / kTileW, gy = oy + ty, gx = ox + (r - ty * kTileW);
-            if (v != 0.0f && gy < G.Hs && gx < G.Ws) atomicAdd(g_src + ((size_t)n * C + c) * HsWs + (size_t)gy * G.Ws + gx, v);
-        }
+    if (IMG && win.live) {
+        emit_row(0);
+        emit_row(1);
+        emit_row(2);
     }
     block_reduce12(gM, partials + ((size_t)n * gridDim.x + blockIdx.x) * 12, lds);
 }

@@ -59,6 +59,8 @@ int main(int argc, char** argv) {
     std::vector<float> ones(B, 1.f); CK(hipMalloc(&g_sums, B * 4)); CK(hipMemcpy(g_sums, ones.data(), B * 4, hipMemcpyHostToDevice));
     size_t n1 = ws_loss(B, H, W), n2 = ws_warp(N, H, W);
     CK(hipMalloc(&w1, n1 ? n1 : 4)); CK(hipMalloc(&w2, n2 ? n2 : 4));
+    float* g_src = nullptr;  // DS_KBENCH_IMG=1: also scatter the source-image gradient
+    if (getenv("DS_KBENCH_IMG")) { CK(hipMalloc(&g_src, N * 3 * HW * 4)); CK(hipMemset(g_src, 0, N * 3 * HW * 4)); }
     hipStream_t st = 0;
     hipEvent_t e[5]; for (auto& x : e) CK(hipEventCreate(&x));
     double t[4] = {0, 0, 0, 0};
@@ -70,7 +72,7 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e[2], st));
         rc = loss_bwd(warped, tgt, idt, aux, g_sums, B, S, H, W, g_warped, st); if (rc) { fprintf(stderr, "loss_bwd rc=%d\n", rc); return 1; }
         CK(hipEventRecord(e[3], st));
-        rc = warp_bwd(K, Kinv, pose, depth, src, g_warped, N, 3, H, W, H, W, g_depth, g_pose, nullptr, w2, n2, st); if (rc) { fprintf(stderr, "warp_bwd rc=%d\n", rc); return 1; }
+        rc = warp_bwd(K, Kinv, pose, depth, src, g_warped, N, 3, H, W, H, W, g_depth, g_pose, g_src, w2, n2, st); if (rc) { fprintf(stderr, "warp_bwd rc=%d\n", rc); return 1; }
         CK(hipEventRecord(e[4], st));
         CK(hipStreamSynchronize(st));
         if (it >= 0) for (int k = 0; k < 4; ++k) { float ms; CK(hipEventElapsedTime(&ms, e[k], e[k + 1])); t[k] += ms; }
