@@ -255,10 +255,12 @@ constexpr int kBwdRows = DS_BWD_ROWS;  // rows per wave: the 12-float pose-gradi
 //   * when the window moves on, the finished row r0 goes to memory with ONE coalesced atomic per texel and channel
 //     (atomic because the windows of neighbouring waves overlap at their edges); about 1.25 atomics per pixel and
 //     channel instead of 4, all of them full aligned lines;
-//   * pixels whose taps do not fit the window (a near pixel among far ones: its disparity differs by more than a texel)
-//     are scattered directly, lane by lane, with four atomics per channel; if more than a few lanes of a row misfit
-//     (strong minification, source larger than the grid) the whole row is.  The result never depends on the path taken.
-// B=12, 192x640, image gradient on: 382 us direct, 213 us LDS tile, 149 us this way with bench.py's random per-pixel
+//   * a pixel whose taps do not fit the window (a near pixel among far ones: its disparity differs by more than a texel)
+//     is broadcast from its lane and taken over by the two lanes that own its columns if rows and columns are still
+//     inside the window, otherwise that lane scatters it directly with four atomics per channel; if more than a few
+//     lanes of a row misfit (strong minification, source larger than the grid) the whole row is scattered directly.
+//     The result never depends on the path taken.
+// B=12, 192x640, image gradient on: 382 us direct, 213 us LDS tile, 128 us this way with bench.py's random per-pixel
 // depth (about 5 % misfits), 91 us with a smooth depth map; 34 us without the image gradient (scripts/img_grad_bench.py).
 struct ImgWindow {
     float a[3][3];   // [channel][window row]
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
                     ok = true;
                 }
             }
-            const bool direct = valid && !(ok && lane_ok);  // this pixel goes to memory with four atomics per channel
+            bool direct = valid && !ok;  // pixels that go to memory with four atomics per channel
             if (ok) {
                 // the pixel's four weights as a 3 (window rows) x 3 (owner columns x-1, x, x+1) stencil
                 const float wat = lane_ok ? t.wa_t : 0.f, wbt = lane_ok ? t.wb_t : 0.f;
@@ -446,6 +448,34 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
                     // the outer columns of the window have no owner lane: the two edge lanes keep those sums
 #pragma unroll
                     for (int s = 0; s < 3; ++s) win.e[c][s] = fmaf(gc, lane == 0 ? kl[s] : kr[s], win.e[c][s]);
+                }
+                // misfit pixels, one at a time: if the tap still lands on columns and rows the window holds, the two owner
+                // lanes take it over (broadcast from the misfit lane); otherwise that lane scatters directly
+                unsigned long long todo = __ballot(valid && !lane_ok);
+                const int col = x + win.cb, col_first = bx * 64 + win.cb;
+                while (todo) {
+                    const int m = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const int mxl = __builtin_amdgcn_readlane(t.xl, m);
+                    const int top = __builtin_amdgcn_readlane(t.y0, m) - win.r0;  // window row of its top texels
+                    if (top >= 0 && top <= 1 && mxl >= col_first && mxl + 1 <= col_first + 63) {
+                        const float mat = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t.wa_t), m));
+                        const float mbt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t.wb_t), m));
+                        const float mab = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t.wa_b), m));
+                        const float mbb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t.wb_b), m));
+                        const float wt = col == mxl ? mat : (col == mxl + 1 ? mbt : 0.f);
+                        const float wb = col == mxl ? mab : (col == mxl + 1 ? mbb : 0.f);
+                        const float k0 = top == 0 ? wt : 0.f, k1 = top == 0 ? wb : wt, k2 = top == 0 ? 0.f : wb;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float mg = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g[c]), m));
+                            win.a[c][0] = fmaf(mg, k0, win.a[c][0]);
+                            win.a[c][1] = fmaf(mg, k1, win.a[c][1]);
+                            win.a[c][2] = fmaf(mg, k2, win.a[c][2]);
+                        }
+                    } else if (lane == m) {
+                        direct = true;
+                    }
                 }
             }
             if (direct) {
