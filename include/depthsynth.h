@@ -70,7 +70,7 @@ int ds_grid_sample_bwd(const float* src, const float* grid_norm, const float* g_
 int ds_warp_fwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src, int N,
                 int C, int Hs, int Ws, int H, int W, float* warped, void* stream);
 
-/* workspace for ds_warp_bwd / ds_fused_bwd pose-gradient partials */
+/* workspace for the pose-gradient partials of ds_warp_bwd and ds_reproject_bwd */
 size_t ds_warp_bwd_workspace_bytes(int N, int H, int W);
 
 /* autograd of ds_warp_fwd: g_depth (N,H,W), g_pose (N,3,4) (deterministic two-stage reduction, no
