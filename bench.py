@@ -359,7 +359,7 @@ def main():
             line["one_stream"] = sequential
         if cold is not None:
             line["cold_cache"] = cold
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU leg is timed at N=1 only
             line["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(line), flush=True)
     if dist is not None:
