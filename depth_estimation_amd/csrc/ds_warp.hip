@@ -267,12 +267,6 @@ struct ImgWindow {
     bool live;
 };
 
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
 template <int C, bool IMG = false>
 __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restrict__ K, const float* __restrict__ Kinv,
                                                             const float* __restrict__ pose,
