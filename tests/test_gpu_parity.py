@@ -492,3 +492,49 @@ def test_full_size_against_oracle_and_properties(de, oracle, B, S, H, W):
             tol = 1e-4 if H * W >= 64 else 5e-4
             assert rel_to_max(N(dd.grad)[b, :, 0], np.stack(gd)) < tol
             assert rel_to_max(N(pp.grad)[b], np.stack(gp)) < tol
+
+
+def test_config4_size_partition_invariance_and_spot_oracle(de, oracle):
+    """BASELINE config 4 (B=64, S=2, 320x1024, 1.8 GB working set): the launch geometry depends on the batch size, the
+    results must not -- the whole batch == the batch run as 40 + 24 targets, bit for bit (maps, depth and pose gradients; the
+    per-target means to 1e-6); first and last target against the oracle; depth metrics of the batch against the oracle."""
+    g = torch.Generator().manual_seed(404)
+    B, S, H, W = 64, 2, 320, 1024
+    src = torch.rand(B, S, 3, H, W, generator=g)
+    tgt = torch.rand(B, 3, H, W, generator=g)
+    depth = 1 + 79 * torch.rand(B, S, 1, H, W, generator=g)
+    vec = 0.01 * torch.randn(B * S, 6, generator=g)
+    K, Kinv = de.fused.intrinsics(W, H)
+    pose_np = oracle.pose_from_vec(vec.numpy()).reshape(B, S, 3, 4)
+    Kd, Kid, srcd, tgtd = K.to(DEV), Kinv.to(DEV), src.to(DEV), tgt.to(DEV)
+
+    def run(lo, hi):
+        dd = depth[lo:hi].to(DEV).requires_grad_(True)
+        pp = T(pose_np[lo:hi]).requires_grad_(True)
+        r = de.fused.fused_reprojection_loss(srcd[lo:hi], tgtd[lo:hi], dd, pp, Kd, Kid)
+        r["loss"].sum().backward()
+        return r, dd.grad, pp.grad
+
+    full, gd, gp = run(0, B)
+    for lo, hi in ((0, 40), (40, B)):
+        part, pgd, pgp = run(lo, hi)
+        for k in ("warped", "out_loss", "idt_loss", "aux"):
+            assert torch.equal(full[k][lo:hi], part[k]), (k, lo)
+        for k in ("loss", "log"):  # per-wave fp32 partials: the row chunks, and with them the grouping, follow the batch size
+            assert float(((full[k][lo:hi] - part[k]).abs() / part[k].abs()).max()) < 1e-6, (k, lo)
+        assert torch.equal(gd[lo:hi], pgd) and torch.equal(gp[lo:hi], pgp)
+        del part, pgd, pgp
+    Kn, Kin = K.numpy(), Kinv.numpy()
+    for b in (0, B - 1):
+        ow = np.stack([oracle.warp(Kn, Kin, pose_np[b, s], depth[b, s].numpy(), src[b, s].numpy(), H, W) for s in range(S)])
+        assert np.array_equal(N(full["warped"][b]), ow)
+        la = oracle.loss_assembly(ow, src[b].numpy(), tgt[b].numpy())
+        assert np.array_equal(N(full["out_loss"][b]), la["out_loss"]) and np.array_equal(N(full["aux"][b]) & 0x1f, la["argmin"])
+        assert abs(float(full["loss"][b]) - la["mean_ratio"]) < 1e-5
+    gt = depth[:, 0].clone()
+    gt[torch.rand(gt.shape, generator=g) < 0.3] = 0.0
+    pred = depth[:, 1].contiguous()
+    m = de.metrics.depth_metrics(pred.to(DEV), gt.to(DEV))
+    o = oracle.depth_metrics(pred.numpy(), gt.numpy())
+    for k in ("rmse", "rmsle", "abs_rel", "sq_rel", "delta1", "n_valid"):
+        assert abs(float(m[k]) - o[k]) < 1e-4 * max(abs(o[k]), 1e-12), k
