@@ -15,6 +15,7 @@
 #define DS_ERR_INVALID_ARG (-1)
 #define DS_ERR_UNSUPPORTED (-2)
 #define DS_ERR_WORKSPACE (-3)
+#define DS_ERR_SCRATCH_LIMIT (-4)
 
 namespace ds {
 

@@ -6,6 +6,7 @@
 #include "ds_common.h"
 #include "ds_warp_dev.h"
 #include <algorithm>
+#include <mutex>
 #include "depthsynth.h"
 
 using namespace ds;
@@ -709,11 +710,58 @@ inline bool resize_geom(ResizeGeom& G, int N, int Hin, int Win, int Hout, int Wo
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// ds_depth_metrics_noalloc: the workspace of ds_depth_metrics in a file-scope device array instead of a caller buffer.
+// `scratch` is a host-side stand-in for the symbol, not a device address: host code only ever uses the per-device pointer
+// hipGetSymbolAddress returns (every GPU the library runs on holds its own copy of the array at its own address).
+// ---------------------------------------------------------------------------------------------------
+constexpr size_t kScratchBytes = DS_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static void* scratch_ptr_of_device[kMaxDevices];  // zero-initialised; filled once per device
+static std::mutex scratch_mutex;
+
+// device address of `scratch` on the current device (looked up on the first call per device); rc = DS_OK, DS_ERR_*, or hipError_t
+static int scratch_device_ptr(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= kMaxDevices) return DS_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (!scratch_ptr_of_device[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        if (!p) return DS_ERR_WORKSPACE;
+        scratch_ptr_of_device[dev] = p;
+    }
+    *out = scratch_ptr_of_device[dev];
+    return DS_OK;
+}
+
+// the launches of ds_depth_metrics; `workspace` is a device pointer of at least ds_metrics_workspace_bytes(B,H,W) bytes,
+// 16-byte aligned.  Every partial and per-image slot that is read has been written by this call: nothing needs clearing.
+static int depth_metrics_launch(const float* pred, const float* gt, int B, int H, int W, float* out, void* workspace,
+                                hipStream_t st) {
+    const int nb = metric_blocks(H * W);
+    const int vec = ((H * W) & 3) == 0 && (((uintptr_t)pred | (uintptr_t)gt) & 15) == 0;
+    float* partials = (float*)workspace;
+    double* per_image = (double*)(partials + (size_t)B * nb * 8);  // 32 * B * nb bytes in: 8-byte aligned
+    hipLaunchKernelGGL(metrics_kernel, dim3(nb, B), dim3(kThreads), 0, st, pred, gt, H * W, vec, partials);
+    DS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(metrics_image_kernel, dim3(B), dim3(kThreads), 0, st, partials, nb, 1.0 / ((double)H * W), per_image);
+    DS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(64), 0, st, per_image, B, out);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
-int ds_version(void) { return 100; }
+int ds_version(void) { return 101; }
 
 const char* ds_error_string(int code) {
     switch (code) {
@@ -721,6 +769,8 @@ const char* ds_error_string(int code) {
         case DS_ERR_INVALID_ARG: return "depthsynth: invalid argument (null pointer or dimension out of range)";
         case DS_ERR_UNSUPPORTED: return "depthsynth: unsupported configuration (e.g. more than DS_MAX_SOURCES sources)";
         case DS_ERR_WORKSPACE: return "depthsynth: workspace missing or too small";
+        case DS_ERR_SCRATCH_LIMIT: return "depthsynth: input needs more than the DS_NOALLOC_SCRATCH_BYTES built-in scratch; "
+                                          "use the entry point that takes a workspace";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "depthsynth: unknown error";
     }
 }
@@ -878,18 +928,16 @@ int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, fl
     if (!pred || !gt || !out || bad_img(B, 1, H, W)) return DS_ERR_INVALID_ARG;
     if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ds_metrics_workspace_bytes(B, H, W))
         return DS_ERR_WORKSPACE;
-    const int nb = metric_blocks(H * W);
-    const int vec = ((H * W) & 3) == 0 && (((uintptr_t)pred | (uintptr_t)gt) & 15) == 0;
-    float* partials = (float*)workspace;
-    double* per_image = (double*)(partials + (size_t)B * nb * 8);  // 32 * B * nb bytes in: 8-byte aligned
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(metrics_kernel, dim3(nb, B), dim3(kThreads), 0, st, pred, gt, H * W, vec, partials);
-    DS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(metrics_image_kernel, dim3(B), dim3(kThreads), 0, st, partials, nb, 1.0 / ((double)H * W), per_image);
-    DS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(64), 0, st, per_image, B, out);
-    DS_CHECK_LAUNCH();
-    return DS_OK;
+    return depth_metrics_launch(pred, gt, B, H, W, out, workspace, (hipStream_t)stream);
+}
+
+int ds_depth_metrics_noalloc(const float* pred, const float* gt, int B, int H, int W, float* out, void* stream) {
+    if (!pred || !gt || !out || bad_img(B, 1, H, W)) return DS_ERR_INVALID_ARG;
+    if (ds_metrics_workspace_bytes(B, H, W) > kScratchBytes) return DS_ERR_SCRATCH_LIMIT;
+    void* ws = nullptr;
+    const int rc = scratch_device_ptr(&ws);
+    if (rc != DS_OK) return rc;
+    return depth_metrics_launch(pred, gt, B, H, W, out, ws, (hipStream_t)stream);
 }
 
 int ds_ingest_u8(const uint8_t* frames, int N, int H, int W, float* out, void* stream) {

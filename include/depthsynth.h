@@ -30,6 +30,7 @@ extern "C" {
 #define DS_ERR_INVALID_ARG (-1)
 #define DS_ERR_UNSUPPORTED (-2)
 #define DS_ERR_WORKSPACE   (-3)
+#define DS_ERR_SCRATCH_LIMIT (-4) /* ds_*_noalloc: the input needs more than the built-in scratch array */
 
 #define DS_MAX_SOURCES 4        /* S per launch of the loss kernels (the reference uses S = SEQ_LEN-1 = 3) */
 #define DS_AUX_ARGMIN_MASK 0x1f /* aux byte: bits 0-4 argmin source, bits 5-7 reserved (0) */
@@ -174,6 +175,17 @@ int ds_smooth_batch_bwd(const float* depths, const float* targets, const float* 
 size_t ds_metrics_workspace_bytes(int B, int H, int W);
 int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, float* out, void* workspace,
                      size_t workspace_bytes, void* stream);
+
+/* ds_depth_metrics without a caller workspace and without any allocation.  No counterpart in the reference: it exists
+ * for callers that cannot allocate device memory around the call (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  The partial sums live in a DS_NOALLOC_SCRATCH_BYTES array inside the library's
+ * device image (one copy per GPU, held until the process ends), so ds_metrics_workspace_bytes(B,H,W) must not exceed
+ * DS_NOALLOC_SCRATCH_BYTES (B * ceil(H*W/2048) <= ~32700; 64 x 320 x 1024 needs 0.33 MB): larger inputs return
+ * DS_ERR_SCRATCH_LIMIT.  Calls on one GPU share that array: calls that overlap in time on one GPU (different streams or
+ * threads) race; order them.  The first call on a device looks the array's address up (hipGetSymbolAddress; no memory
+ * is allocated), so make one call outside a capture first.  Same kernels and results as ds_depth_metrics. */
+#define DS_NOALLOC_SCRATCH_BYTES (1u << 20)
+int ds_depth_metrics_noalloc(const float* pred, const float* gt, int B, int H, int W, float* out, void* stream);
 
 /* Input pipeline to the device: torchvision.transforms.functional.to_tensor on the resized frame (dataset.py:51,110):
  * frames (N,H,W,3) uint8 interleaved -> out (N,3,H,W) fp32 = value / 255.  The PIL resize itself stays on the host.

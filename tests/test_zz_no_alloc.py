@@ -1,0 +1,69 @@
+"""ds_depth_metrics_noalloc (include/depthsynth.h): the no-allocation variant of ds_depth_metrics, whose partial sums live
+in a device array inside the library instead of a caller workspace.  Through the C ABI, against ds_depth_metrics itself:
+same kernels, so the eight outputs must be bit-identical (integer counts and float means alike) -- on two calls in a row,
+the second on a smaller input (the shared array keeps the first call's contents), then on a ragged size, then the
+size limit.  Collected last (test_zz_*): it must pass alone in a fresh process and after the other GPU tests."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _inputs(B, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    gt = 1 + 79 * torch.rand(B, 1, H, W, generator=g)
+    gt[torch.rand(B, 1, H, W, generator=g) < 0.3] = 0.0
+    pred = 1 + 79 * torch.rand(B, 1, H, W, generator=g)
+    return pred.to(DEV), gt.to(DEV)
+
+
+def _both(L, pred, gt):
+    lib = L.lib()
+    B, _, H, W = pred.shape
+    st = L.stream()
+    want = torch.full((8,), -1.0, dtype=torch.float32, device=DEV)
+    nb = lib.ds_metrics_workspace_bytes(B, H, W)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    L.check(lib.ds_depth_metrics(pred.data_ptr(), gt.data_ptr(), B, H, W, want.data_ptr(), ws.data_ptr(), nb, st),
+            "ds_depth_metrics")
+    got = torch.full((8,), -2.0, dtype=torch.float32, device=DEV)
+    L.check(lib.ds_depth_metrics_noalloc(pred.data_ptr(), gt.data_ptr(), B, H, W, got.data_ptr(), st),
+            "ds_depth_metrics_noalloc")
+    torch.cuda.synchronize()
+    return got.cpu().numpy(), want.cpu().numpy()
+
+
+def test_noalloc_depth_metrics_matches_workspace_form():
+    from depth_estimation_amd import _lib as L
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    # two calls in a row, the second with a smaller input
+    for B, H, W, seed in ((6, 192, 640, 1), (2, 40, 96, 2), (3, 37, 131, 3), (1, 1, 1, 4)):
+        pred, gt = _inputs(B, H, W, seed)
+        got, want = _both(L, pred, gt)
+        assert np.array_equal(got, want), (B, H, W, got, want)
+        assert got[7] == float((gt > 0).sum())          # the valid-pixel count is an integer and exact
+    # the same call twice gives the same bits (nothing left over from the call before matters)
+    pred, gt = _inputs(2, 40, 96, 2)
+    a, _ = _both(L, pred, gt)
+    b, _ = _both(L, pred, gt)
+    assert np.array_equal(a, b)
+
+
+def test_noalloc_rejects_inputs_beyond_the_scratch():
+    from depth_estimation_amd import _lib as L
+    lib = L.lib()
+    # workspace need grows with B * ceil(H*W / 2048) * 32 bytes; the built-in array is 1 MiB
+    B, H, W = 64, 1024, 1024
+    assert lib.ds_metrics_workspace_bytes(B, H, W) > (1 << 20)
+    one = torch.zeros(1, dtype=torch.float32, device=DEV)   # never dereferenced: the call is refused before any launch
+    out = torch.zeros(8, dtype=torch.float32, device=DEV)
+    rc = lib.ds_depth_metrics_noalloc(one.data_ptr(), one.data_ptr(), B, H, W, out.data_ptr(), L.stream())
+    assert rc == -4
+    assert b"scratch" in lib.ds_error_string(rc)
+    with pytest.raises(RuntimeError, match="scratch"):
+        L.check(rc, "ds_depth_metrics_noalloc")
+    assert lib.ds_depth_metrics_noalloc(0, one.data_ptr(), 1, 1, 1, out.data_ptr(), L.stream()) == -1
