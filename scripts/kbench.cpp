@@ -114,6 +114,21 @@ int main(int argc, char** argv) {
         double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters;
         printf("   split into %d parts on %d streams: %.4f ms per step\n", parts, parts, ms);
     }
+    // ---- the forward loss as two launches of the G = S kernel (warped groups, identity groups) instead of one G = 2S launch
+    typedef int (*rl_fwd_t)(const float*, const float*, long long, long long, int, int, int, int, float*, uint8_t*, void*);
+    if (auto rl_fwd = (rl_fwd_t)dlsym(h, "ds_reprojection_loss_fwd")) {
+        double tw = 0, ti = 0;
+        for (int it = -3; it < iters; ++it) {
+            CK(hipEventRecord(e[0], st));
+            rl_fwd(warped, tgt, 3 * (long long)HW, 0, B, S, H, W, out, aux, st);
+            CK(hipEventRecord(e[1], st));
+            rl_fwd(src, tgt, 3 * (long long)HW, 0, B, S, H, W, idt, nullptr, st);
+            CK(hipEventRecord(e[2], st));
+            CK(hipStreamSynchronize(st));
+            if (it >= 0) { float ms; CK(hipEventElapsedTime(&ms, e[0], e[1])); tw += ms; CK(hipEventElapsedTime(&ms, e[1], e[2])); ti += ms; }
+        }
+        printf("   reprojection_loss_fwd alone: warped groups %.4f ms, identity groups %.4f ms\n", tw / iters, ti / iters);
+    }
     std::vector<float> hs(B * 2); CK(hipMemcpy(hs.data(), sums, B * 8, hipMemcpyDeviceToHost));
     printf("%-40s B=%d S=%d %dx%d  warp_fwd %.4f  loss_fwd %.4f  loss_bwd %.4f  warp_bwd %.4f ms  (sum %.4f)  loss[0]=%.6f\n", argv[1], B, S, H, W,
            t[0] / iters, t[1] / iters, t[2] / iters, t[3] / iters, (t[0] + t[1] + t[2] + t[3]) / iters, hs[0]);
