@@ -5,17 +5,26 @@
 
 A "step" is one pass of the hot path (train.py:72-92 batched: warp fwd -> SSIM+L1/min/auto-mask fwd ->
 its backward -> warp backward with depth and pose gradients) over one synthetic batch that is already
-resident in HBM.  Kernels are called through the C ABI (include/depthsynth.h) with pre-allocated outputs.
+resident in HBM.  Kernels are called through the C ABI (include/depthsynth.h) with pre-allocated outputs, the
+whole batch on ONE stream, every step ordered after the previous one (train.py:102-109 joins every batch).
 The batch is sharded over ranks with no data-path collective (weak scaling: every rank owns B targets);
 the only cross-rank traffic is the barrier and a MAX all-reduce of the elapsed time.
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks (fresh child processes, one per
+GPU, RCCL rendezvous on 127.0.0.1) and waits for them; under torch.distributed.run it uses the ranks it is given.
+`--workload full_step` is BASELINE config 5: the whole train.py step with stand-in networks and the gradient
+all-reduce (scripts/full_step.py holds the harness).
+
 Rank 0 prints ONE JSON line.  `value` = warped pixels (B*S*H*W per rank, all ranks) per second.
-`roofline` is for the dominant kernel (HIP events on the launch stream, inside this run).
-`cpu_baseline` = the CPU oracle (a scalar C port of the reference's arithmetic) on a bounded sample.
+`roofline` is for the dominant kernel (HIP events on the launch stream, inside this run); `roofline.valu` prices the
+same kernel against the VALU issue peak (instruction counts from the committed PMC pass, profiles/pmc.json).
+`cpu_baseline` = the CPU oracle (a C port of the reference's arithmetic) on a bounded sample, on the host's cores.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,12 +41,22 @@ WORKLOADS = {
     "b12_s2_192x640_pyramid4_fwdbwd": dict(B=12, S=2, H=192, W=640, scales=4, image_grad=True),
     # config 4: the HBM-resident-set-exceeds-cache case; the step ends with the depth-metrics reduction on (B,1,H,W)
     "b64_s2_320x1024_fwdbwd": dict(B=64, S=2, H=320, W=1024, scales=1, metrics=True),
+    # config 5: the whole train.py step (stand-in networks, fused loss path, gradient all-reduce, clip, Adam)
+    "full_step": dict(B=2, S=3, H=192, W=640, scales=1),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+METRIC = "warped px/s (Gpix/s) fwd+bwd reproj loss @192x640, % HBM roofline, 1-8 GPU"
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+VALU_ISSUE_NS = 0.83         # one fp32 VALU wave instruction per SIMD per 2 cycles at 2.4 GHz (profiles/r01_ubench4_valu_stream.txt)
+
+
+def step_alg_bytes_per_target_px(S, C=3, image_grad=False):
+    """forward 4(S+2CS+C+2) + backward 4(2S+2CS+C+2) [+4CS with the image gradient] bytes per TARGET pixel
+    (= 80 B per warped pixel at S=2, C=3; 92 with the image gradient)."""
+    return 4 * (S + 2 * C * S + C + 2) + 4 * (2 * S + 2 * C * S + C + 2) + (4 * C * S if image_grad else 0)
 
 
 class Scale:
-    """All device buffers of one (B,S,H,W) problem + the four C-ABI calls of a step."""
+    """All device buffers of one (B,S,H,W) problem + the C-ABI calls of a step."""
 
     def __init__(self, de, B, S, H, W, dev, seed, image_grad, metrics=False):
         from depth_estimation_amd import _lib as L
@@ -90,9 +109,9 @@ class Scale:
                                                    p(self.g_src), p(self.ws_warp), self.ws_warp_n, st),
         }
         if metrics:
-            self.calls["metrics"] = lambda st: lib.ds_depth_metrics(p(self.pred), p(self.gt), B, H, W, p(self.met),
+            self.calls["metrics"] = lambda st: lib.ds_depth_metrics(p(self.pred), p(self.gt), B, H, W, p(self.met), 0,
                                                                     p(self.ws_met), self.ws_met_n, st)
-        # algorithmic HBM bytes of each call: every input read once, every output written once (DESIGN.md)
+        # algorithmic HBM bytes of each call: every input read once, every output written once (DESIGN.md 4)
         px, tp = self.N * H * W, B * H * W
         self.alg_bytes = {
             "warp_fwd": px * (4 + 12 + 12),                       # depth + src (gather) -> warped
@@ -102,6 +121,8 @@ class Scale:
         }
         if metrics:
             self.alg_bytes["metrics"] = tp * 8                    # pred + gt
+        # what BASELINE.md prices the step with: SURVEY 8d's bytes of the fused path (no warped / g_warped round trips)
+        self.step_bytes = tp * step_alg_bytes_per_target_px(S, 3, image_grad) + (tp * 8 if metrics else 0)
 
     def step(self, st):
         if self.g_src is not None:
@@ -114,7 +135,7 @@ class Scale:
 
 def build_problem(de, wl, dev, rank, image_grad, parts=1):
     """One Scale per (pyramid level, sub-batch).  With parts > 1 the B targets of a level are split into `parts`
-    independent sub-batches (own buffers, own workspaces), which the step launches on `parts` HIP streams."""
+    independent sub-batches (own buffers, own workspaces), which the pipelined variant launches on `parts` HIP streams."""
     scales = []
     for i in range(wl["scales"]):
         # small pyramid levels are launch-bound: splitting them only adds launches
@@ -127,19 +148,27 @@ def build_problem(de, wl, dev, rank, image_grad, parts=1):
     return scales
 
 
-def cpu_baseline(wl, budget_s=12.0):
-    """The CPU oracle (scalar C port, 1 thread) on whole samples of the same workload, ~budget_s seconds."""
+def host_threads():
+    """Threads for the CPU leg: the box exports its CPU share as OMP_NUM_THREADS (os.cpu_count() shows the whole machine)."""
+    try:
+        n = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    except ValueError:
+        n = 0
+    return n if n > 0 else (os.cpu_count() or 1)
+
+
+def cpu_baseline(wl, budget_s=8.0):
+    """The CPU oracle (C port, OpenMP over image rows) on whole samples of the same workload, per-sample loop as
+    train.py:39: ~budget_s seconds on all host threads (the reported figure), then ~budget_s / 2 on one thread."""
     import numpy as np
     from oracle import ds_oracle as o
     o.build()
-    o.set_threads(1)
     S, H, W = wl["S"], wl["H"], wl["W"]
     rng = np.random.default_rng(0)
     src = rng.random((S, 3, H, W), dtype=np.float32)
     tgt = rng.random((3, H, W), dtype=np.float32)
     depth = (1 + 79 * rng.random((S, H, W), dtype=np.float32)).astype(np.float32)
     pose = o.pose_from_vec((0.01 * rng.standard_normal((S, 6))).astype(np.float32))
-    import torch as _t
     from depth_estimation_amd.fused import intrinsics
     K, Kinv = [a.numpy() for a in intrinsics(W, H)]
 
@@ -150,15 +179,69 @@ def cpu_baseline(wl, budget_s=12.0):
         for s in range(S):
             o.warp_bwd(K, Kinv, pose[s], depth[s], src[s], gw[s], H, W, False)
 
-    one_sample()
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
+    def timed(threads, budget):
+        o.set_threads(threads)
         one_sample()
-        n += 1
-    dt = time.perf_counter() - t0
-    return dict(value=n * S * H * W / dt / 1e9, unit="Gpix/s", cores=1, kind="port",
-                sample=f"{n} samples (1 target x {S} sources, {H}x{W}, single scale) fwd+bwd in {dt:.1f} s, "
-                       f"oracle/ds_oracle.c single thread; host has {os.cpu_count()} logical CPUs")
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            one_sample()
+            n += 1
+        dt = time.perf_counter() - t0
+        return n, dt, n * S * H * W / dt / 1e9
+
+    cores = host_threads()
+    n, dt, v = timed(cores, budget_s)
+    n1, dt1, v1 = timed(1, budget_s / 2)
+    return dict(value=v, unit="Gpix/s", cores=cores, kind="port", one_thread_value=v1,
+                sample=f"{n} samples (1 target x {S} sources, {H}x{W}, single scale) fwd+bwd in {dt:.1f} s on {cores} "
+                       f"threads (OpenMP over rows, per-sample loop as train.py:39), oracle/ds_oracle.c; {n1} samples in "
+                       f"{dt1:.1f} s on 1 thread; os.cpu_count() = {os.cpu_count()}")
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """Start n ranks of this script as fresh child processes (nothing in this process has touched the GPU) and wait."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def dry_run(args, rank, world):
+    """--dry: the launcher / rendezvous / reduction path of a multi-rank run on the CPU (gloo), no kernels."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        size = dist.get_world_size()
+    else:
+        size = 1
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "Gpix/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dry": True, "backend": "gloo", "world_size": size,
+                          "max_elapsed_s": float(t.item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -169,21 +252,27 @@ def main():
     ap.add_argument("--workload", default="b12_s2_192x640_fwdbwd", choices=sorted(WORKLOADS))
     ap.add_argument("--image-grad", action="store_true", help="also scatter the source-image gradient")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
     ap.add_argument("--cold-steps", type=int, default=20, help="single steps timed after a cache flush (0 = skip)")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="sub-batches per step, each on its own HIP stream: the memory-bound warp kernels of one overlap "
-                         "the VALU-bound loss kernels of the other (1 = whole batch on one stream)")
-    ap.add_argument("--join", action="store_true",
-                    help="join the side streams into the current stream after every step (a training loop's optimizer step "
-                         "needs all gradients): the sub-batches then overlap within a step only")
+    ap.add_argument("--pipelined", type=int, default=3,
+                    help="also report the un-joined variant: this many independent sub-batches, each on its own HIP "
+                         "stream, never joined between steps (0 = skip); never the headline")
+    ap.add_argument("--dry", action="store_true", help="launcher / rendezvous check on the CPU (gloo), no kernels")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))   # before anything here touches the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        return dry_run(args, rank, world)
+    if args.workload == "full_step":
+        from scripts import full_step
+        return full_step.main(args, rank, local_rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -196,57 +285,13 @@ def main():
 
     import depth_estimation_amd as de
     wl = WORKLOADS[args.workload]
-    parts = max(1, min(args.streams, wl["B"]))
     image_grad = args.image_grad or wl.get("image_grad", False)
-    scales = build_problem(de, wl, dev, rank, image_grad, parts)
+    scales = build_problem(de, wl, dev, rank, image_grad, 1)
     st = torch.cuda.current_stream().cuda_stream
-    # one stream per (pyramid level, sub-batch): the levels are independent calls too (BASELINE config 3)
-    side_streams = [torch.cuda.Stream() for _ in range(len(scales))] if parts > 1 else []
 
     def step():
-        if parts == 1:
-            for sc in scales:
-                sc.step(st)
-            return
-        # the four calls of every sub-batch, issued phase by phase so that each stream always has work queued
         for sc in scales:
-            if sc.g_src is not None:
-                sc.g_src.zero_()
-        if args.join:
-            cur = torch.cuda.current_stream()
-            for ss in side_streams:
-                ss.wait_stream(cur)
-        for name in scales[0].names:
-            for j, sc in enumerate(scales):
-                rc = sc.calls[name](side_streams[j].cuda_stream)
-                if rc != 0:
-                    sc.L.check(rc, name)
-        if args.join:
-            for ss in side_streams:
-                cur.wait_stream(ss)
-
-    graph = None
-    if args.graph:
-        # capture one step (all sub-batches, all streams: fork from / join into the capturing stream) and replay it
-        cap = torch.cuda.Stream()
-        with torch.cuda.stream(cap):
-            step()
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=cap):
-                if parts == 1:
-                    for sc in scales:
-                        sc.step(torch.cuda.current_stream().cuda_stream)
-                else:
-                    cur = torch.cuda.current_stream()
-                    for ss in side_streams:
-                        ss.wait_stream(cur)
-                    step()
-                    for ss in side_streams:
-                        cur.wait_stream(ss)
-        run = graph.replay
-    else:
-        run = step
+            sc.step(st)
 
     def barrier():
         torch.cuda.synchronize()
@@ -254,11 +299,11 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        run()
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run()
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -268,6 +313,8 @@ def main():
 
     warped_px_rank = sum(sc.N * sc.H * sc.W for sc in scales)
     value = world * warped_px_rank * args.steps / elapsed / 1e9
+    step_bytes = sum(sc.step_bytes for sc in scales)
+    kernel_sum_bytes = sum(sum(sc.alg_bytes.values()) for sc in scales)
 
     # cold-cache figure: the 192x640 working set fits the 256 MiB Infinity Cache, so also time single
     # steps after a 512 MiB write has pushed it out (host clock around one synchronised step: includes ~10 us of
@@ -290,28 +337,7 @@ def main():
                 "steps": args.cold_steps, "note": "median of single synchronised steps, each after a 512 MiB cache flush"}
 
     # per-kernel durations: HIP events on the launch stream around each call, inside the same step sequence
-    # (whole batch of the finest level on the current stream, whatever --streams says: kernels do not overlap here)
     names = scales[0].names
-    step_bytes = sum(sum(sc.alg_bytes.values()) for sc in scales)
-    if parts > 1:
-        del scales
-        scales = build_problem(de, wl, dev, rank, image_grad, 1)
-    # the same K steps with the whole batch on the current stream (no overlap between sub-batches): what a caller sees that
-    # orders every step after the previous one; reported beside `value`
-    sequential = None
-    if parts > 1:
-        for _ in range(args.warmup):
-            for sc in scales:
-                sc.step(st)
-        torch.cuda.synchronize()
-        s0 = time.perf_counter()
-        for _ in range(args.steps):
-            for sc in scales:
-                sc.step(st)
-        torch.cuda.synchronize()
-        sdt = time.perf_counter() - s0
-        sequential = {"value": round(warped_px_rank * args.steps / sdt / 1e9, 4), "unit": "Gpix/s (this rank)",
-                      "ms_per_step": round(sdt / args.steps * 1e3, 5), "launch": "whole batch on one stream"}
     sc0 = scales[0]
     ev = {n: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
           for n in names}
@@ -329,34 +355,85 @@ def main():
     kern_ms = {n: sum(a.elapsed_time(b) for a, b in ev[n]) / args.steps for n in names}
     dom = max(names, key=lambda n: kern_ms[n])
     achieved = sc0.alg_bytes[dom] / (kern_ms[dom] * 1e-3) / 1e9
-    # HBM bytes per launch from the PMC passes of the same command (profiles/traffic.json; null if not collected)
-    traffic = None
+    # per launch, from the PMC passes of the same command (profiles/pmc.json: HBM bytes = FETCH_SIZE x 2 + WRITE_SIZE
+    # with the gfx950 unit correction; VALU wave instructions = SQ_INSTS_VALU); null if not collected
+    pmc = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            traffic = json.load(fh).get(args.workload, {}).get(dom)
+        with open(os.path.join(ROOT, "profiles", "pmc.json")) as fh:
+            pmc = json.load(fh).get(args.workload, {}).get(dom, {})
     except (OSError, ValueError):
         pass
+    traffic, valu_insts = pmc.get("hbm_bytes"), pmc.get("valu_wave_insts")
+    valu = None
+    if valu_insts:
+        props = torch.cuda.get_device_properties(dev)
+        simds = 4 * props.multi_processor_count
+        peak = simds / (VALU_ISSUE_NS * 1e-9) / 1e9          # G wave-instructions / s
+        got = valu_insts / (kern_ms[dom] * 1e-3) / 1e9
+        valu = {"achieved": round(got, 1), "peak": round(peak, 1), "unit": "G wave-instr/s", "frac": round(got / peak, 4),
+                "insts_per_launch": valu_insts, "simds": simds}
+    # what binds the dominant kernel: the resource it uses the larger fraction of
+    hbm_frac = achieved / HBM_PEAK_GBS
+    binding = "valu" if (valu is not None and valu["frac"] > hbm_frac) else "hbm"
+
+    # the un-joined variant (round 1's headline): independent sub-batches on their own streams, pipelined across steps
+    pipelined = None
+    if rank == 0 and args.pipelined > 1 and wl["B"] >= args.pipelined:
+        parts = build_problem(de, wl, dev, rank, image_grad, args.pipelined)
+        side = [torch.cuda.Stream() for _ in parts]
+
+        def pstep():
+            for sc in parts:
+                if sc.g_src is not None:
+                    sc.g_src.zero_()
+            for name in parts[0].names:
+                for j, sc in enumerate(parts):
+                    rc = sc.calls[name](side[j].cuda_stream)
+                    if rc != 0:
+                        sc.L.check(rc, name)
+
+        n = max(10, args.steps // 2)
+        for _ in range(min(args.warmup, 10)):
+            pstep()
+        torch.cuda.synchronize()
+        p0 = time.perf_counter()
+        for _ in range(n):
+            pstep()
+        torch.cuda.synchronize()
+        pdt = time.perf_counter() - p0
+        pipelined = {"value": round(warped_px_rank * n / pdt / 1e9, 4), "unit": "Gpix/s (this rank)",
+                     "ms_per_step": round(pdt / n * 1e3, 5), "steps": n,
+                     "launch": f"{args.pipelined} independent sub-batches on {args.pipelined} streams, not joined between steps"}
+        del parts
 
     if rank == 0:
+        ms = elapsed / args.steps * 1e3
         line = {
-            "metric": "warped px/s (Gpix/s) fwd+bwd reproj loss @192x640, % HBM roofline, 1-8 GPU",
+            "metric": METRIC,
             "value": round(value, 4), "unit": "Gpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "targets_per_gpu": wl["B"], "sources_per_target": wl["S"],
                        "height": wl["H"], "width": wl["W"], "scales": wl["scales"], "image_grad": bool(image_grad),
                        "metrics_reduce": bool(wl.get("metrics", False)),
-                       "launch": ("hipgraph" if args.graph else "eager") + ("" if parts == 1 else f", {parts} sub-batches on {parts} streams" + (", joined every step" if args.join else "")),
+                       "launch": "eager, whole batch on one stream, steps ordered (joined)",
                        "parallelism": f"batch-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "alg_bytes_per_launch": sc0.alg_bytes[dom], "avg_ms": round(kern_ms[dom], 5)},
+                         "frac": round(hbm_frac, 4), "traffic": traffic,
+                         "alg_bytes_per_launch": sc0.alg_bytes[dom], "avg_ms": round(kern_ms[dom], 5),
+                         "valu": valu, "binding_resource": binding},
             "kernels_ms": {n: round(kern_ms[n], 5) for n in names},
-            "step_alg_GBps": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
-            "step_frac_of_hbm_peak": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            # the step against the HBM roofline by BASELINE.md's accounting (80 B per warped px at S=2, 92 with
+            # the image gradient): bytes the fused path must move, not the bytes the unfused kernels do move
+            "step_alg_bytes": step_bytes,
+            "step_alg_GBps": round(world * step_bytes / (ms * 1e-3) / 1e9, 1),
+            "step_frac_of_hbm_peak": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            # for comparison: the sum over the launched kernels of each one's own input+output bytes (includes the
+            # warped and g_warped round trips between them)
+            "kernel_sum_alg_GBps": round(kernel_sum_bytes / (ms * 1e-3) / 1e9, 1),
         }
-        if sequential is not None:
-            line["one_stream"] = sequential
+        if pipelined is not None:
+            line["pipelined_unjoined"] = pipelined
         if cold is not None:
             line["cold_cache"] = cold
         if not args.no_cpu and world == 1:  # the CPU leg is timed at N=1 only

@@ -58,8 +58,8 @@ _SIGNATURES = {
     "ds_smooth_batch_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp]),
     "ds_ingest_u8": (_i, [_fp, _i, _i, _i, _fp, _fp]),
     "ds_metrics_workspace_bytes": (_sz, [_i, _i, _i]),
-    "ds_depth_metrics": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _sz, _fp]),
-    "ds_depth_metrics_noalloc": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp]),
+    "ds_depth_metrics": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _fp, _sz, _fp]),
+    "ds_depth_metrics_noalloc": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _fp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -536,7 +536,8 @@ __global__ __launch_bounds__(kThreads) void metrics_kernel(const float* __restri
 // Two short kernels, fixed summation order (deterministic): one workgroup per image sums the image's block partials in
 // double (every thread one or a few independent 32-byte loads) and forms the image's terms; one wave sums over the images.
 __global__ __launch_bounds__(kThreads) void metrics_image_kernel(const float* __restrict__ partials, int nblk, double inv_hw,
-                                                                 double* __restrict__ per_image) {
+                                                                 double* __restrict__ per_image,
+                                                                 long long* __restrict__ counts) {
     __shared__ double lds[kThreads / 64][8];
     const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -559,6 +560,9 @@ __global__ __launch_bounds__(kThreads) void metrics_image_kernel(const float* __
         double t = 0.0;
         for (int w = 0; w < kThreads / 64; ++w) t += lds[w][k];
         per_image[(size_t)b * 8 + k] = k < 2 ? sqrt(t * inv_hw) : (k < 7 ? t * inv_hw : t);
+        // the three threshold counts and the valid count are sums of 0/1: every fp32 block partial (<= 2048) and the
+        // double sum over them is an exact integer
+        if (counts && k >= 4) counts[(size_t)b * 4 + (k - 4)] = (long long)t;
     }
 }
 
@@ -742,15 +746,16 @@ static int scratch_device_ptr(void** out) {
 
 // the launches of ds_depth_metrics; `workspace` is a device pointer of at least ds_metrics_workspace_bytes(B,H,W) bytes,
 // 16-byte aligned.  Every partial and per-image slot that is read has been written by this call: nothing needs clearing.
-static int depth_metrics_launch(const float* pred, const float* gt, int B, int H, int W, float* out, void* workspace,
-                                hipStream_t st) {
+static int depth_metrics_launch(const float* pred, const float* gt, int B, int H, int W, float* out, long long* counts,
+                                void* workspace, hipStream_t st) {
     const int nb = metric_blocks(H * W);
     const int vec = ((H * W) & 3) == 0 && (((uintptr_t)pred | (uintptr_t)gt) & 15) == 0;
     float* partials = (float*)workspace;
     double* per_image = (double*)(partials + (size_t)B * nb * 8);  // 32 * B * nb bytes in: 8-byte aligned
     hipLaunchKernelGGL(metrics_kernel, dim3(nb, B), dim3(kThreads), 0, st, pred, gt, H * W, vec, partials);
     DS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(metrics_image_kernel, dim3(B), dim3(kThreads), 0, st, partials, nb, 1.0 / ((double)H * W), per_image);
+    hipLaunchKernelGGL(metrics_image_kernel, dim3(B), dim3(kThreads), 0, st, partials, nb, 1.0 / ((double)H * W), per_image,
+                       counts);
     DS_CHECK_LAUNCH();
     hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(64), 0, st, per_image, B, out);
     DS_CHECK_LAUNCH();
@@ -923,21 +928,22 @@ size_t ds_metrics_workspace_bytes(int B, int H, int W) {
     return (size_t)B * metric_blocks(H * W) * 8 * sizeof(float) + (size_t)B * 8 * sizeof(double);
 }
 
-int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, float* out, void* workspace,
-                     size_t workspace_bytes, void* stream) {
+int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, float* out, long long* counts,
+                     void* workspace, size_t workspace_bytes, void* stream) {
     if (!pred || !gt || !out || bad_img(B, 1, H, W)) return DS_ERR_INVALID_ARG;
     if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ds_metrics_workspace_bytes(B, H, W))
         return DS_ERR_WORKSPACE;
-    return depth_metrics_launch(pred, gt, B, H, W, out, workspace, (hipStream_t)stream);
+    return depth_metrics_launch(pred, gt, B, H, W, out, counts, workspace, (hipStream_t)stream);
 }
 
-int ds_depth_metrics_noalloc(const float* pred, const float* gt, int B, int H, int W, float* out, void* stream) {
+int ds_depth_metrics_noalloc(const float* pred, const float* gt, int B, int H, int W, float* out, long long* counts,
+                             void* stream) {
     if (!pred || !gt || !out || bad_img(B, 1, H, W)) return DS_ERR_INVALID_ARG;
     if (ds_metrics_workspace_bytes(B, H, W) > kScratchBytes) return DS_ERR_SCRATCH_LIMIT;
     void* ws = nullptr;
     const int rc = scratch_device_ptr(&ws);
     if (rc != DS_OK) return rc;
-    return depth_metrics_launch(pred, gt, B, H, W, out, ws, (hipStream_t)stream);
+    return depth_metrics_launch(pred, gt, B, H, W, out, counts, ws, (hipStream_t)stream);
 }
 
 int ds_ingest_u8(const uint8_t* frames, int N, int H, int W, float* out, void* stream) {

@@ -39,10 +39,13 @@ def regularization_term(depths: torch.Tensor, target_imgs: torch.Tensor) -> torc
 
 def depth_metrics(pred_depths: torch.Tensor, depths: torch.Tensor) -> dict:
     """All of metrics.py:100-153 in one pass, plus delta<1.25^k (not in the reference; same all-pixel
-    denominator) and the valid-pixel count.  Returns 0-dim tensors (no host sync)."""
-    o = ops.depth_metrics(pred_depths, depths)
+    denominator) and the valid-pixel count.  Returns 0-dim tensors (no host sync), plus "counts": (B,4) int64, per
+    image the exact numbers of valid pixels with max(p/g, g/p) < 1.25, 1.25^2, 1.25^3 and of valid (gt > 0) pixels."""
+    o, counts = ops.depth_metrics(pred_depths, depths, want_counts=True)
     names = ("rmse", "rmsle", "abs_rel", "sq_rel", "delta1", "delta2", "delta3", "n_valid")
-    return {k: o[i] for i, k in enumerate(names)}
+    r = {k: o[i] for i, k in enumerate(names)}
+    r["counts"] = counts
+    return r
 
 
 def rmse(pred_depths, depths: torch.Tensor) -> torch.Tensor:

@@ -417,8 +417,9 @@ def train_step(K, Kinv, pose, depth, src, target, smooth_scale: float):
 # ----------------------------------------------------------------------------------------------------
 # forward-only ops
 # ----------------------------------------------------------------------------------------------------
-def depth_metrics(pred, gt) -> torch.Tensor:
-    """pred, gt (B,1,H,W) -> (8,) fp32: rmse, rmsle, abs_rel, sq_rel, delta1, delta2, delta3, n_valid."""
+def depth_metrics(pred, gt, want_counts: bool = False):
+    """pred, gt (B,1,H,W) -> (8,) fp32: rmse, rmsle, abs_rel, sq_rel, delta1, delta2, delta3, n_valid; with want_counts
+    also (B,4) int64: per image the exact counts under the three thresholds and of valid pixels."""
     pred, gt = L.dev_f32(pred.detach(), "pred_depths"), L.dev_f32(gt.detach(), "depths")
     L.same_device(pred, gt)
     if pred.shape != gt.shape or pred.dim() < 3:
@@ -427,11 +428,12 @@ def depth_metrics(pred, gt) -> torch.Tensor:
     hw = pred.numel() // b
     h, w = pred.shape[-2], hw // pred.shape[-2]
     out = torch.empty(8, dtype=torch.float32, device=pred.device)
+    counts = torch.empty(b, 4, dtype=torch.int64, device=pred.device) if want_counts else None
     nb = L.lib().ds_metrics_workspace_bytes(b, h, w)
     ws = L.workspace.get(nb, pred.device)
-    L.check(L.lib().ds_depth_metrics(pred.data_ptr(), gt.data_ptr(), b, h, w, out.data_ptr(), ws.data_ptr(), nb, L.stream()),
-            "ds_depth_metrics")
-    return out
+    L.check(L.lib().ds_depth_metrics(pred.data_ptr(), gt.data_ptr(), b, h, w, out.data_ptr(), L.ptr(counts), ws.data_ptr(), nb,
+                                     L.stream()), "ds_depth_metrics")
+    return (out, counts) if want_counts else out
 
 
 def _depths_arg(depths):

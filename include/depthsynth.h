@@ -171,10 +171,12 @@ int ds_smooth_batch_bwd(const float* depths, const float* targets, const float* 
 
 /* metrics.rmse / rmsle / abs_rel / sq_rel (metrics.py:100-153; test.py:78-81) in ONE pass over
  * pred, gt (B,1,H,W): out (8) fp32 = rmse, rmsle, abs_rel, sq_rel, delta<1.25, <1.25^2, <1.25^3 (not in
- * the reference: same all-pixel denominator, parity unpinned), number of valid pixels.  workspace 16-byte aligned. */
+ * the reference: same all-pixel denominator, parity unpinned), number of valid pixels.  counts (B,4) int64, optional
+ * (NULL to skip): per image the exact numbers of valid pixels under the three thresholds and of valid (gt > 0) pixels,
+ * so that callers can renormalise by the valid count.  workspace 16-byte aligned. */
 size_t ds_metrics_workspace_bytes(int B, int H, int W);
-int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, float* out, void* workspace,
-                     size_t workspace_bytes, void* stream);
+int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, float* out, long long* counts,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ds_depth_metrics without a caller workspace and without any allocation.  No counterpart in the reference: it exists
  * for callers that cannot allocate device memory around the call (code under HIP graph capture, tight serving loops,
@@ -185,7 +187,8 @@ int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, fl
  * threads) race; order them.  The first call on a device looks the array's address up (hipGetSymbolAddress; no memory
  * is allocated), so make one call outside a capture first.  Same kernels and results as ds_depth_metrics. */
 #define DS_NOALLOC_SCRATCH_BYTES (1u << 20)
-int ds_depth_metrics_noalloc(const float* pred, const float* gt, int B, int H, int W, float* out, void* stream);
+int ds_depth_metrics_noalloc(const float* pred, const float* gt, int B, int H, int W, float* out, long long* counts,
+                             void* stream);
 
 /* Input pipeline to the device: torchvision.transforms.functional.to_tensor on the resized frame (dataset.py:51,110):
  * frames (N,H,W,3) uint8 interleaved -> out (N,3,H,W) fp32 = value / 255.  The PIL resize itself stays on the host.

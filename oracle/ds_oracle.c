@@ -556,6 +556,23 @@ DSO_API double dso_regularization_term(const float* depths, const float* targets
  * reference defines them (masked-out pixels count as zeros in a mean over ALL H*W pixels, then mean
  * over B).  out[4..6] = delta<1.25, <1.25^2, <1.25^3 with the same all-pixel denominator (NOT in the
  * reference: parity unpinned), out[7] = number of valid (gt>0) pixels summed over B. */
+/* per image: numbers of valid pixels under the three thresholds, number of valid pixels (integers; (B,4)) */
+DSO_API void dso_depth_metric_counts(const float* pred, const float* gt, int B, size_t HW, long long* counts) {
+    for (int b = 0; b < B; ++b) {
+        long long c[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < HW; ++i) {
+            float p = pred[(size_t)b * HW + i], g = gt[(size_t)b * HW + i];
+            if (!(g > 0.0f)) continue;
+            float r = fmaxf(p / g, g / p);
+            c[0] += r < 1.25f;
+            c[1] += r < 1.5625f;
+            c[2] += r < 1.953125f;
+            c[3] += 1;
+        }
+        for (int k = 0; k < 4; ++k) counts[(size_t)b * 4 + k] = c[k];
+    }
+}
+
 DSO_API void dso_depth_metrics(const float* pred, const float* gt, int B, size_t HW, double* out) {
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int b = 0; b < B; ++b) {

@@ -39,6 +39,7 @@ def lib() -> C.CDLL:
             build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.dso_depth_metrics.argtypes = [_f32p, _f32p, C.c_int, C.c_size_t, _f64p]
+        _lib.dso_depth_metric_counts.argtypes = [_f32p, _f32p, C.c_int, C.c_size_t, C.POINTER(C.c_longlong)]
         _lib.dso_depth_from_costs.argtypes = [_f32p, C.c_int, C.c_int, C.c_size_t, C.c_int, _f32p]
         _lib.dso_regularization_term.restype = C.c_double
         _lib.dso_regularization_term.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _f32p]
@@ -185,6 +186,15 @@ def depth_metrics(pred, gt) -> dict:
     lib().dso_depth_metrics(_p(pred), _p(gt), B, hw, out.ctypes.data_as(_f64p))
     keys = ("rmse", "rmsle", "abs_rel", "sq_rel", "delta1", "delta2", "delta3", "n_valid")
     return dict(zip(keys, out.tolist()))
+
+
+def depth_metric_counts(pred, gt) -> np.ndarray:
+    """a15 as integers: (B,4) int64 = per image #(delta<1.25), #(<1.25^2), #(<1.25^3), #(gt>0)."""
+    pred, gt = _f(pred), _f(gt)
+    B = pred.shape[0]
+    out = np.zeros((B, 4), np.int64)
+    lib().dso_depth_metric_counts(_p(pred), _p(gt), B, pred.size // B, out.ctypes.data_as(C.POINTER(C.c_longlong)))
+    return out
 
 
 def synthesize_from_depths(K, Kinv, pose, depths, W: int, H: int, src) -> np.ndarray:

@@ -129,6 +129,40 @@ int main(int argc, char** argv) {
         }
         printf("   reprojection_loss_fwd alone: warped groups %.4f ms, identity groups %.4f ms\n", tw / iters, ti / iters);
     }
+    // ---- overlap probe: warp_fwd (memory-bound) and the identity groups' loss (VALU-bound) are independent.  Sequential
+    // on one stream against concurrent on two streams (fork/join by events, every iteration), wall clock.
+    if (auto rl_fwd = (rl_fwd_t)dlsym(h, "ds_reprojection_loss_fwd")) {
+        hipStream_t s1, s2; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        hipEvent_t ef, ej; CK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+        auto wall = [&](auto&& body) {
+            for (int i = 0; i < 5; ++i) body();
+            CK(hipDeviceSynchronize());
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < iters; ++i) body();
+            CK(hipDeviceSynchronize());
+            return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters;
+        };
+        double seq = wall([&] {
+            warp_fwd(K, Kinv, pose, depth, src, N, 3, H, W, H, W, warped, s1);
+            rl_fwd(src, tgt, 3 * (long long)HW, 0, B, S, H, W, idt, nullptr, s1);
+        });
+        double conc = wall([&] {
+            CK(hipEventRecord(ef, s1)); CK(hipStreamWaitEvent(s2, ef, 0));
+            warp_fwd(K, Kinv, pose, depth, src, N, 3, H, W, H, W, warped, s1);
+            rl_fwd(src, tgt, 3 * (long long)HW, 0, B, S, H, W, idt, nullptr, s2);
+            CK(hipEventRecord(ej, s2)); CK(hipStreamWaitEvent(s1, ej, 0));
+        });
+        double w_only = wall([&] { warp_fwd(K, Kinv, pose, depth, src, N, 3, H, W, H, W, warped, s1); });
+        double i_only = wall([&] { rl_fwd(src, tgt, 3 * (long long)HW, 0, B, S, H, W, idt, nullptr, s1); });
+        double full = wall([&] {
+            warp_fwd(K, Kinv, pose, depth, src, N, 3, H, W, H, W, warped, s1);
+            loss_fwd(warped, src, tgt, B, S, H, W, out, idt, aux, sums, w1, n1, s1);
+            loss_bwd(warped, tgt, idt, aux, g_sums, B, S, H, W, g_warped, s1);
+            warp_bwd(K, Kinv, pose, depth, src, g_warped, N, 3, H, W, H, W, g_depth, g_pose, g_src, w2, n2, s1);
+        });
+        printf("   wall clock, back to back: warp_fwd %.4f, identity loss %.4f, both sequential %.4f, on two streams %.4f; whole step %.4f ms\n",
+               w_only, i_only, seq, conc, full);
+    }
     std::vector<float> hs(B * 2); CK(hipMemcpy(hs.data(), sums, B * 8, hipMemcpyDeviceToHost));
     printf("%-40s B=%d S=%d %dx%d  warp_fwd %.4f  loss_fwd %.4f  loss_bwd %.4f  warp_bwd %.4f ms  (sum %.4f)  loss[0]=%.6f\n", argv[1], B, S, H, W,
            t[0] / iters, t[1] / iters, t[2] / iters, t[3] / iters, (t[0] + t[1] + t[2] + t[3]) / iters, hs[0]);

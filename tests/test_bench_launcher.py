@@ -1,0 +1,38 @@
+"""bench.py --gpus N starts its own ranks: exercised here on the CPU with --dry (gloo, no kernels)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry", "--steps", "3", "--warmup", "1", *extra],
+                       env=env, capture_output=True, text=True, timeout=300)
+    return p
+
+
+def test_self_launch_two_ranks():
+    p = _run("--gpus", "2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout          # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["dry"] is True
+    assert line["steps"] == 3 and line["warmup"] == 1
+    assert line["max_elapsed_s"] >= 0.02       # the MAX over ranks: rank 1 sleeps 20 ms
+
+
+def test_single_rank_needs_no_launcher():
+    p = _run("--gpus", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["world_size"] == 1
+
+
+def test_world_size_mismatch_is_an_error():
+    p = _run("--gpus", "2", env_extra={"WORLD_SIZE": "1", "RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr

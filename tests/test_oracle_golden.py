@@ -160,3 +160,14 @@ def test_depth_metrics(oracle):
     for k, thr in (("delta1", 1.25), ("delta2", 1.25 ** 2), ("delta3", 1.25 ** 3)):
         ref = np.mean([(r[b] < thr).sum() / r[b].size for b in range(r.shape[0])])
         assert abs(m[k] - ref) < 2e-3
+    # the counts behind them are integers: exact against a float32 numpy count (same IEEE divides, same thresholds)
+    B = d["pred"].shape[0]
+    p32, g32 = d["pred"].reshape(B, -1), d["gt"].reshape(B, -1)
+    v32 = g32 > 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r32 = np.maximum(p32 / g32, g32 / p32)
+    want = np.stack([(v32 & (r32 < np.float32(t))).sum(1) for t in (1.25, 1.5625, 1.953125)] + [v32.sum(1)], axis=1)
+    got = oracle.depth_metric_counts(d["pred"], d["gt"])
+    assert got.dtype == np.int64 and np.array_equal(got, want)
+    for i, k in enumerate(("delta1", "delta2", "delta3")):
+        assert abs(m[k] - (want[:, i] / p32.shape[1]).mean()) < 1e-12

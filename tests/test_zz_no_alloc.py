@@ -27,12 +27,16 @@ def _both(L, pred, gt):
     want = torch.full((8,), -1.0, dtype=torch.float32, device=DEV)
     nb = lib.ds_metrics_workspace_bytes(B, H, W)
     ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
-    L.check(lib.ds_depth_metrics(pred.data_ptr(), gt.data_ptr(), B, H, W, want.data_ptr(), ws.data_ptr(), nb, st),
-            "ds_depth_metrics")
+    want_c = torch.full((B, 4), -1, dtype=torch.int64, device=DEV)
+    L.check(lib.ds_depth_metrics(pred.data_ptr(), gt.data_ptr(), B, H, W, want.data_ptr(), want_c.data_ptr(), ws.data_ptr(),
+                                 nb, st), "ds_depth_metrics")
     got = torch.full((8,), -2.0, dtype=torch.float32, device=DEV)
-    L.check(lib.ds_depth_metrics_noalloc(pred.data_ptr(), gt.data_ptr(), B, H, W, got.data_ptr(), st),
+    got_c = torch.full((B, 4), -2, dtype=torch.int64, device=DEV)
+    L.check(lib.ds_depth_metrics_noalloc(pred.data_ptr(), gt.data_ptr(), B, H, W, got.data_ptr(), got_c.data_ptr(), st),
             "ds_depth_metrics_noalloc")
     torch.cuda.synchronize()
+    assert torch.equal(got_c, want_c)
+    assert torch.equal(got_c[:, 3].cpu(), (gt > 0).flatten(1).sum(1).cpu())
     return got.cpu().numpy(), want.cpu().numpy()
 
 
@@ -61,9 +65,9 @@ def test_noalloc_rejects_inputs_beyond_the_scratch():
     assert lib.ds_metrics_workspace_bytes(B, H, W) > (1 << 20)
     one = torch.zeros(1, dtype=torch.float32, device=DEV)   # never dereferenced: the call is refused before any launch
     out = torch.zeros(8, dtype=torch.float32, device=DEV)
-    rc = lib.ds_depth_metrics_noalloc(one.data_ptr(), one.data_ptr(), B, H, W, out.data_ptr(), L.stream())
+    rc = lib.ds_depth_metrics_noalloc(one.data_ptr(), one.data_ptr(), B, H, W, out.data_ptr(), 0, L.stream())
     assert rc == -4
     assert b"scratch" in lib.ds_error_string(rc)
     with pytest.raises(RuntimeError, match="scratch"):
         L.check(rc, "ds_depth_metrics_noalloc")
-    assert lib.ds_depth_metrics_noalloc(0, one.data_ptr(), 1, 1, 1, out.data_ptr(), L.stream()) == -1
+    assert lib.ds_depth_metrics_noalloc(0, one.data_ptr(), 1, 1, 1, out.data_ptr(), 0, L.stream()) == -1

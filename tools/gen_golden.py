@@ -295,10 +295,37 @@ def case_resize(name):
     print(name, "ok")
 
 
+LOSS_CASES = ["synth_24x80", "synth_oov_24x80", "synth_ties_24x80", "synth_zcross_24x80", "synth_odd_19x37", "real_48x160"]
+
+
+def case_ssim_grad(name):
+    """autograd of metrics.reprojection_error alone (metrics.py:21-51) w.r.t. preds under a seeded upstream gradient, on
+    the warped images and targets the loss fixtures already hold.  Reads those fixtures, changes none of them: the
+    forward map recomputed here must reproduce their stored CRC."""
+    rec = {}
+    for case in LOSS_CASES:
+        d = np.load(os.path.join(OUT, case + ".npz"))
+        warped = torch.from_numpy(d["warped"]).requires_grad_(True)
+        S = warped.shape[0]
+        target_imgs = torch.stack([torch.from_numpy(d["target"])] * S, dim=0)
+        gen = torch.Generator().manual_seed(zlib.crc32(case.encode()) & 0xffff)
+        g_up = torch.randn(warped.shape, generator=gen)
+        ssim = ref_metrics.reprojection_error(warped, target_imgs)
+        assert int(crc(npf(ssim))) == int(d["crc_ssim_warped"]), case       # existing fixtures are reproduced bit for bit
+        ssim.backward(g_up)
+        rec[case + "/g_up"] = npf(g_up)
+        rec[case + "/g_ssim"] = npf(warped.grad)
+        print(f"{name}: {case} |g|max = {warped.grad.abs().max().item():.4f}")
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if sys.argv[1:] == ["resize"]:                                # added later; leaves the other fixtures untouched
         case_resize("resize_vectors")
+        return
+    if sys.argv[1:] == ["ssim_grad"]:                             # round 2; reads the loss fixtures, rewrites none
+        case_ssim_grad("ssim_grad")
         return
     case_real("real_48x160", 160, 48, full=True, sub=1)
     case_real("real_192x640", 640, 192, full=False, sub=8)       # BASELINE config 1
