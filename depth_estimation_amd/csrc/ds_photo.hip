@@ -22,6 +22,7 @@
 #include "ds_common.h"
 #include "depthsynth.h"
 #include <math.h>
+#include <stdlib.h>
 
 using namespace ds;
 
@@ -872,6 +873,7 @@ inline Geom make_fwd_lds_geom(int B, int H, int W) {
     long long nby = (8 * capacity + bands - 1) / bands;
     const int max_nby = H / 12 > 1 ? H / 12 : 1;
     if (nby > max_nby) nby = max_nby;
+    if (const char* e = getenv("DS_FWD_NBY")) nby = atoi(e);
     g.RB = (H + (int)nby - 1) / (int)nby;
     g.nby = (H + g.RB - 1) / g.RB;
     g.nblocks = B * g.nbx * g.nby;
@@ -926,6 +928,7 @@ inline Geom make_bwd_geom(int B, int H, int W) {
     long long nby = (8 * capacity + per_chunk - 1) / per_chunk;
     const int max_nby = H / 16 > 1 ? H / 16 : 1;
     if (nby > max_nby) nby = max_nby;
+    if (const char* e = getenv("DS_BWD_NBY")) nby = atoi(e);
     g.RB = (H + (int)nby - 1) / (int)nby;
     g.nby = (H + g.RB - 1) / g.RB;
     g.nwaves = B * g.nbx * g.nby * 3;

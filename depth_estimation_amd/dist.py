@@ -56,7 +56,12 @@ class GradBuckets:
     (pose 11.2 M + decoder 25.9 M + convgru 0.5 M fp32) to overlap with backward.
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 25 << 20):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 25 << 20, average: bool = True):
+        """average=True divides the summed gradients by the world size (every rank holds a replica of the same loss
+        mean); average=False leaves the SUM, which is what a batch that train.py:88 SUMS over its samples needs when the
+        samples are sharded over ranks."""
+        self.average = average
+        self._hooks, self._pending, self._handles, self._group = [], [], [], None
         self.params = [p for p in params if p.requires_grad]
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, cur_bytes = [], 0
@@ -93,9 +98,70 @@ class GradBuckets:
         self.unpack(world)
         return None
 
+
+    # ---- overlapped form: all-reduce every bucket as soon as backward has produced its last gradient ----------------
+    def attach(self, group: Optional[dist.ProcessGroup] = None) -> None:
+        """Register one post-accumulate hook per parameter.  During backward, the bucket whose last gradient has just been
+        accumulated is packed and its all-reduce launched asynchronously (RCCL runs it on its own stream), so the
+        collectives of early buckets overlap with the rest of backward.  Call begin() before every backward and
+        finish() after it."""
+        if self._hooks:
+            return
+        self._group = group
+        index = {}
+        for bi, bucket in enumerate(self.buckets):
+            for p in bucket:
+                index[p] = bi
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, bi=index[p]: self._grad_ready(bi)))
+
+    def detach(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def begin(self) -> None:
+        self._pending = [len(b) for b in self.buckets]
+        self._handles = [None] * len(self.buckets)
+
+    def _launch(self, bi: int) -> None:
+        flat, off = self._flat[bi], 0
+        for p in self.buckets[bi]:
+            n = p.numel()
+            if p.grad is None:
+                flat[off:off + n].zero_()
+            else:
+                flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        if dist.is_initialized() and dist.get_world_size(self._group) > 1:
+            self._handles[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+        else:
+            self._handles[bi] = False
+
+    def _grad_ready(self, bi: int) -> None:
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def finish(self) -> None:
+        """Launch the buckets backward never completed (parameters without a gradient this step), wait for every
+        collective and write the reduced gradients back into p.grad."""
+        for bi in range(len(self.buckets)):
+            if self._handles[bi] is None:
+                self._launch(bi)
+        for h in self._handles:
+            if h:
+                h.wait()
+        self.unpack()
+
+    def nbytes(self) -> int:
+        return sum(f.numel() for f in self._flat) * 4
+
     def unpack(self, world: Optional[int] = None):
         if world is None:
-            world = dist.get_world_size() if dist.is_initialized() else 1
+            world = dist.get_world_size(self._group) if dist.is_initialized() else 1
+        if not self.average:
+            world = 1
         for flat, bucket in zip(self._flat, self.buckets):
             off = 0
             for p in bucket:

@@ -21,12 +21,32 @@ def reprojection_error(preds: torch.Tensor, targets: torch.Tensor) -> torch.Tens
     return ops.ssim_loss(preds, targets)
 
 
-def reprojection_loss(preds: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
-    """metrics.py:54-72 -- 0.85*SSIM + 0.15*L1, mean over channels, min over dim 0: (S,3,H,W) x2 -> (1,1,H,W)."""
+_shared_target_cache = {}  # (data_ptr, version, shape) of the last target stack examined -> bool
+
+
+def _targets_are_one_image(targets: torch.Tensor) -> bool:
+    """train.py:80 builds the target stack with torch.stack([target] * S): S identical copies.  An expanded view shows it
+    in its strides; a real stack only in its values, which costs one comparison kernel and a host sync (the reference's
+    loop syncs per sample anyway, train.py:92) -- remembered for the second call on the same tensor (train.py:84-85)."""
+    if targets.shape[0] == 1 or targets.stride(0) == 0:
+        return True
+    key = (targets.data_ptr(), targets._version, tuple(targets.shape))
+    hit = _shared_target_cache.get(key)
+    if hit is None:
+        hit = bool((targets[1:] == targets[:1]).all().item())
+        _shared_target_cache.clear()
+        _shared_target_cache[key] = hit
+    return hit
+
+
+def reprojection_loss(preds: torch.Tensor, targets: torch.Tensor, shared_target: bool | None = None) -> torch.Tensor:
+    """metrics.py:54-72 -- 0.85*SSIM + 0.15*L1, mean over channels, min over dim 0: (S,3,H,W) x2 -> (1,1,H,W).
+    shared_target (not in the reference): True if every targets[s] is the same image (one launch for all sources instead
+    of one per source; same result), None = find out."""
     if preds.dim() != 4 or targets.shape != preds.shape:
         raise RuntimeError(f"expected preds and targets (S,3,H,W); got {tuple(preds.shape)}, {tuple(targets.shape)}")
     s, c, h, w = preds.shape
-    shared = targets.stride(0) == 0  # an expanded single target (train.py:80 stacks, which copies)
+    shared = _targets_are_one_image(targets) if shared_target is None else bool(shared_target)
     tg = targets[0].unsqueeze(0) if shared else targets.unsqueeze(0)
     out, _ = ops.reprojection_loss(preds.unsqueeze(0), tg, shared)
     return out.reshape(1, 1, h, w)
