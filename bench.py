@@ -108,6 +108,14 @@ class Scale:
                                                    p(self.g_warped), N, 3, H, W, H, W, p(self.g_depth), p(self.g_pose),
                                                    p(self.g_src), p(self.ws_warp), self.ws_warp_n, st),
         }
+        # the step as ONE call (forward + backward launches and a single merged finalize); the image-gradient scatter is
+        # only in the four-call form
+        self.ws_step_n = self.lib.ds_loss_step_fwdbwd_workspace_bytes(B, S, H, W)
+        self.ws_step = torch.empty(self.ws_step_n, dtype=torch.uint8, device=dev)
+        self.one_call = None if image_grad else (lambda st: lib.ds_loss_step_fwdbwd(
+            p(self.K), p(self.Kinv), p(self.pose), p(self.depth), p(self.src), p(self.tgt), 0, B, S, H, W, p(self.warped),
+            p(self.out), p(self.idt), p(self.aux), p(self.sums), p(self.g_warped), p(self.g_depth), p(self.g_pose),
+            p(self.ws_step), self.ws_step_n, st))
         if metrics:
             self.calls["metrics"] = lambda st: lib.ds_depth_metrics(p(self.pred), p(self.gt), B, H, W, p(self.met), 0,
                                                                     p(self.ws_met), self.ws_met_n, st)
@@ -124,7 +132,16 @@ class Scale:
         # what BASELINE.md prices the step with: SURVEY 8d's bytes of the fused path (no warped / g_warped round trips)
         self.step_bytes = tp * step_alg_bytes_per_target_px(S, 3, image_grad) + (tp * 8 if metrics else 0)
 
-    def step(self, st):
+    def step(self, st, separate=False):
+        if self.one_call is not None and not separate:
+            rc = self.one_call(st)
+            if rc != 0:
+                self.L.check(rc, "ds_loss_step_fwdbwd")
+            if "metrics" in self.calls:
+                rc = self.calls["metrics"](st)
+                if rc != 0:
+                    self.L.check(rc, "metrics")
+            return
         if self.g_src is not None:
             self.g_src.zero_()
         for name in self.names:
@@ -416,7 +433,8 @@ def main():
             "config": {"workload": args.workload, "targets_per_gpu": wl["B"], "sources_per_target": wl["S"],
                        "height": wl["H"], "width": wl["W"], "scales": wl["scales"], "image_grad": bool(image_grad),
                        "metrics_reduce": bool(wl.get("metrics", False)),
-                       "launch": "eager, whole batch on one stream, steps ordered (joined)",
+                       "launch": "eager, whole batch on one stream, steps ordered (joined); " +
+                                 ("four C-ABI calls per level" if image_grad else "one C-ABI call per step (ds_loss_step_fwdbwd)"),
                        "parallelism": f"batch-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(hbm_frac, 4), "traffic": traffic,

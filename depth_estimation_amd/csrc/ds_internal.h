@@ -1,0 +1,64 @@
+// ds_internal.h -- what the translation units of libdepthsynth.so share with each other and with nobody else
+// (hidden visibility: none of this is part of the C ABI in include/depthsynth.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define DS_HIDDEN __attribute__((visibility("hidden")))
+
+namespace ds {
+
+// ---- fixed-order finalisation of partial sums (deterministic: one wave, strided double accumulation, xor tree) ----------
+// per-image sums of the forward loss kernel's per-workgroup partials (ratio, out) -> means (2 floats)
+__device__ __forceinline__ void loss_finalize_wave(const float* __restrict__ wave_partials, int b, int waves_per_image,
+                                                   double inv_hw, float* __restrict__ sums, int lane) {
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = lane; i < waves_per_image; i += 64) {
+        a0 += (double)wave_partials[2 * ((size_t)b * waves_per_image + i) + 0];
+        a1 += (double)wave_partials[2 * ((size_t)b * waves_per_image + i) + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a0 += __shfl_xor(a0, o, 64);
+        a1 += __shfl_xor(a1, o, 64);
+    }
+    if (lane == 0) {
+        sums[2 * b + 0] = (float)(a0 * inv_hw);
+        sums[2 * b + 1] = (float)(a1 * inv_hw);
+    }
+}
+
+// partials (N, nblk, 12) of the warp backward -> g_pose (N,12)
+__device__ __forceinline__ void pose_finalize_wave(const float* __restrict__ partials, int n, int nblk,
+                                                   float* __restrict__ g_pose, int lane) {
+    double a[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) a[i] = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+        const float* q = partials + ((size_t)n * nblk + b) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) a[i] += (double)q[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a[i] += __shfl_xor(a[i], o, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) g_pose[n * 12 + i] = (float)a[i];
+    }
+}
+
+// ---- launchers without their finalize kernel (ds_step.hip merges the finalisations of a step into one launch) --------
+// forward loss kernel of ds_fused_loss_fwd; *waves_per_image = partial-sum slots per image in `workspace`
+DS_HIDDEN int fused_loss_fwd_partials(const float* warped, const float* src, const float* target, int B, int S, int H, int W,
+                                      float* out_loss, float* idt_loss, uint8_t* aux, void* workspace,
+                                      size_t workspace_bytes, int* waves_per_image, hipStream_t stream);
+// main kernel of ds_warp_bwd; *nblk = pose-gradient partials per image in `workspace`
+DS_HIDDEN int warp_bwd_partials(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                                const float* g_warped, int N, int C, int Hs, int Ws, int H, int W, float* g_depth,
+                                float* g_src, void* workspace, size_t workspace_bytes, int* nblk, hipStream_t stream);
+
+}  // namespace ds

@@ -20,9 +20,9 @@
                    // global loads, 2 = no workgroup barriers (wrong results; timing only)
 #endif
 #include "ds_common.h"
+#include "ds_internal.h"
 #include "depthsynth.h"
 #include <math.h>
-#include <stdlib.h>
 
 using namespace ds;
 
@@ -439,21 +439,7 @@ __global__ __launch_bounds__(64 * kWaves) void photo_fwd_dpp_kernel(PhotoFwdPara
 // per-image sums of the wave partials, fixed order, double accumulation -> means (B,2)
 __global__ void loss_finalize_kernel(const float* __restrict__ wave_partials, int waves_per_image, double inv_hw,
                                      float* __restrict__ sums) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    double a0 = 0.0, a1 = 0.0;
-    for (int i = lane; i < waves_per_image; i += 64) {
-        a0 += (double)wave_partials[2 * ((size_t)b * waves_per_image + i) + 0];
-        a1 += (double)wave_partials[2 * ((size_t)b * waves_per_image + i) + 1];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        a0 += __shfl_xor(a0, o, 64);
-        a1 += __shfl_xor(a1, o, 64);
-    }
-    if (lane == 0) {
-        sums[2 * b + 0] = (float)(a0 * inv_hw);
-        sums[2 * b + 1] = (float)(a1 * inv_hw);
-    }
+    loss_finalize_wave(wave_partials, blockIdx.x, waves_per_image, inv_hw, sums, threadIdx.x);
 }
 
 // =====================================================================================================
@@ -577,7 +563,7 @@ __global__ __launch_bounds__(64 * kWaves, S >= 4 ? 3 : 4) void photo_bwd_kernel(
     const rsrc_t wp = make_rsrc((FUSED ? P.idt : P.g_out) + (size_t)b * HW);
     const rsrc_t ap = make_rsrc(P.aux + (size_t)b * HW);
     const rsrc_t gp = make_rsrc(P.g_preds + (size_t)b * P.pred_stride_b);
-    const float gscale = FUSED ? P.g_sums[b] * P.inv_hw : 1.0f;
+    const float gscale = FUSED ? (P.g_sums ? P.g_sums[b] * P.inv_hw : P.inv_hw) : 1.0f;
     float (*lr)[kLdsRow] = lds_raw[wave];
     float (*lk)[kLdsRow] = lds_k[wave];
 
@@ -865,15 +851,33 @@ inline bool fwd_uses_lds(int S, bool idt) { return (idt ? 2 * S : S) <= 6; }
 // (gpurun_out/kb14.txt): 320x1024 B=64 0.561 / 0.529 / 0.510 / 0.506 ms with 1 / 2 / 4 / 8 chunks per band, 192x640
 // B=12 flat between 8 and 24 chunks.  Rule: about eight rounds of workgroups, but chunks of at least 12 rows.
 // Pure function of (B,H,W): workspace size and launch derive the same geometry.
-inline Geom make_fwd_lds_geom(int B, int H, int W) {
+// Small launches (fewer than ~4 rounds even with the shortest chunks) are a different regime: the tail decides.  1920
+// workgroups on 1024 slots run as one full round and one at 7/8 fill; 960 workgroups with chunks twice as long finish
+// sooner (B=12, 192x640: 50.3 -> 47.7 us; gpurun_out/r02_kb1_nby_sweep.txt), and a launch a little over one round is the
+// worst case (+10 %).  So: if the launch cannot reach four rounds, use whole rounds -- the largest chunk count whose
+// workgroups fill k resident rounds exactly or stay just below.
+inline long long pick_chunks(long long per_chunk, long long capacity, int max_nby) {
+    long long nby = (8 * capacity + per_chunk - 1) / per_chunk;   // about eight rounds
+    if (nby <= max_nby) return nby;
+    const double rounds_at_max = (double)per_chunk * max_nby / (double)capacity;
+    if (rounds_at_max >= 4.0) return max_nby;
+    long long k = (long long)rounds_at_max;
+    if (k < 1) k = 1;
+    nby = k * capacity / per_chunk;
+    if (nby > max_nby) nby = max_nby;
+    return nby < 1 ? 1 : nby;
+}
+
+inline Geom make_fwd_lds_geom(int B, int H, int W, int groups) {
     Geom g;
     g.nbx = (W + 63) / 64;
-    const long long capacity = simd_count();  // workgroups resident at once: 4 per CU = one per SIMD
+    // workgroups resident at once: one wave per SIMD each, as many per CU as the VGPR count of the variant allows
+    // (111 VGPRs at G = 4: four; 68 at G = 2: seven)
+    const long long per_cu = groups <= 1 ? 8 : (groups == 2 ? 7 : (groups == 3 ? 5 : (groups == 4 ? 4 : 3)));
+    const long long capacity = (long long)simd_count() / 4 * per_cu;
     const long long bands = (long long)B * g.nbx;
-    long long nby = (8 * capacity + bands - 1) / bands;
     const int max_nby = H / 12 > 1 ? H / 12 : 1;
-    if (nby > max_nby) nby = max_nby;
-    if (const char* e = getenv("DS_FWD_NBY")) nby = atoi(e);
+    const long long nby = pick_chunks(bands, capacity, max_nby);
     g.RB = (H + (int)nby - 1) / (int)nby;
     g.nby = (H + g.RB - 1) / g.RB;
     g.nblocks = B * g.nbx * g.nby;
@@ -881,7 +885,7 @@ inline Geom make_fwd_lds_geom(int B, int H, int W) {
     return g;
 }
 inline Geom make_fwd_geom(int B, int H, int W, int S, bool idt) {
-    return fwd_uses_lds(S, idt) ? make_fwd_lds_geom(B, H, W) : make_geom(B, H, W, 1, 62, 1.0);
+    return fwd_uses_lds(S, idt) ? make_fwd_lds_geom(B, H, W, idt ? 2 * S : S) : make_geom(B, H, W, 1, 62, 1.0);
 }
 
 inline bool bad_dims(int B, int S, int H, int W) {
@@ -925,10 +929,8 @@ inline Geom make_bwd_geom(int B, int H, int W) {
     g.nbx = (W + 61) / 62;
     const long long capacity = (long long)simd_count() * 4;  // units resident at once (four waves per SIMD)
     const long long per_chunk = (long long)B * g.nbx * 3;
-    long long nby = (8 * capacity + per_chunk - 1) / per_chunk;
     const int max_nby = H / 16 > 1 ? H / 16 : 1;
-    if (nby > max_nby) nby = max_nby;
-    if (const char* e = getenv("DS_BWD_NBY")) nby = atoi(e);
+    const long long nby = pick_chunks(per_chunk, capacity, max_nby);
     g.RB = (H + (int)nby - 1) / (int)nby;
     g.nby = (H + g.RB - 1) / g.RB;
     g.nwaves = B * g.nbx * g.nby * 3;
@@ -1022,38 +1024,34 @@ int ds_reprojection_loss_bwd(const float* preds, const float* targets, long long
 
 size_t ds_fused_loss_workspace_bytes(int B, int H, int W) {
     if (B <= 0 || H < 2 || W < 2) return 0;
-    // enough for either forward kernel variant (the entry point has no S)
-    const Geom g1 = make_fwd_geom(B, H, W, 1, true), g2 = make_fwd_geom(B, H, W, DS_MAX_SOURCES, true);
-    const size_t n1 = (size_t)g1.nwaves, n2 = (size_t)g2.nblocks * kWaves;
-    return (n1 > n2 ? n1 : n2) * 2 * sizeof(float);
+    // enough for every forward kernel variant (the entry point has no S)
+    size_t n = 0;
+    for (int S = 1; S <= DS_MAX_SOURCES; ++S) {
+        const Geom g = make_fwd_geom(B, H, W, S, true);
+        const size_t k = fwd_uses_lds(S, true) ? (size_t)g.nwaves : (size_t)g.nblocks * kWaves;
+        if (k > n) n = k;
+    }
+    return n * 2 * sizeof(float);
 }
 
 int ds_fused_loss_fwd(const float* warped, const float* src, const float* target, int B, int S, int H, int W,
                       float* out_loss, float* idt_loss, uint8_t* aux, float* sums, void* workspace,
                       size_t workspace_bytes, void* stream) {
-    if (!warped || !src || !target || !out_loss || !idt_loss || !aux || !sums || bad_dims(B, S, H, W))
-        return DS_ERR_INVALID_ARG;
-    if (S > DS_MAX_SOURCES) return DS_ERR_UNSUPPORTED;
-    if (!workspace || workspace_bytes < ds_fused_loss_workspace_bytes(B, H, W)) return DS_ERR_WORKSPACE;
-    const long long HW = (long long)H * W;
-    PhotoFwdParams P{};
-    P.preds = warped; P.src = src; P.target = target;
-    P.pred_stride_b = (long long)S * 3 * HW;
-    P.tgt_stride_b = 3 * HW;
-    P.B = B; P.H = H; P.W = W;
-    P.out = out_loss; P.idt = idt_loss; P.aux = aux; P.wave_partials = (float*)workspace;
-    Geom g;
-    int rc = launch_photo_fwd<true>(S, P, &g, (hipStream_t)stream);
+    if (!sums) return DS_ERR_INVALID_ARG;
+    int wpi = 0;
+    int rc = ds::fused_loss_fwd_partials(warped, src, target, B, S, H, W, out_loss, idt_loss, aux, workspace, workspace_bytes,
+                                         &wpi, (hipStream_t)stream);
     if (rc != DS_OK) return rc;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const float*)workspace,
-                       g.nbx * g.nby, 1.0 / (double)HW, sums);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, wpi,
+                       1.0 / ((double)H * W), sums);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }
 
 int ds_fused_loss_bwd(const float* warped, const float* target, const float* idt_loss, const uint8_t* aux,
                       const float* g_sums, int B, int S, int H, int W, float* g_warped, void* stream) {
-    if (!warped || !target || !idt_loss || !aux || !g_sums || !g_warped || bad_dims(B, S, H, W)) return DS_ERR_INVALID_ARG;
+    // g_sums may be NULL: unit upstream gradient for every target
+    if (!warped || !target || !idt_loss || !aux || !g_warped || bad_dims(B, S, H, W)) return DS_ERR_INVALID_ARG;
     if (S > DS_MAX_SOURCES) return DS_ERR_UNSUPPORTED;
     const Geom g = make_bwd_geom(B, H, W);
     const long long HW = (long long)H * W;
@@ -1068,3 +1066,23 @@ int ds_fused_loss_bwd(const float* warped, const float* target, const float* idt
 }
 
 }  // extern "C"
+
+int ds::fused_loss_fwd_partials(const float* warped, const float* src, const float* target, int B, int S, int H, int W,
+                                float* out_loss, float* idt_loss, uint8_t* aux, void* workspace, size_t workspace_bytes,
+                                int* waves_per_image, hipStream_t stream) {
+    if (!warped || !src || !target || !out_loss || !idt_loss || !aux || bad_dims(B, S, H, W)) return DS_ERR_INVALID_ARG;
+    if (S > DS_MAX_SOURCES) return DS_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < ds_fused_loss_workspace_bytes(B, H, W)) return DS_ERR_WORKSPACE;
+    const long long HW = (long long)H * W;
+    PhotoFwdParams P{};
+    P.preds = warped; P.src = src; P.target = target;
+    P.pred_stride_b = (long long)S * 3 * HW;
+    P.tgt_stride_b = 3 * HW;
+    P.B = B; P.H = H; P.W = W;
+    P.out = out_loss; P.idt = idt_loss; P.aux = aux; P.wave_partials = (float*)workspace;
+    Geom g;
+    int rc = launch_photo_fwd<true>(S, P, &g, stream);
+    if (rc != DS_OK) return rc;
+    *waves_per_image = g.nbx * g.nby;
+    return DS_OK;
+}

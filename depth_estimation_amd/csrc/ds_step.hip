@@ -10,7 +10,26 @@
 // independent sub-batches ACROSS steps instead, which needs no support here.
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include "ds_common.h"
+#include "ds_internal.h"
 #include "depthsynth.h"
+
+namespace {
+
+// the two fixed-order finalisations of a step in ONE launch: blocks [0,B) the per-image loss means, blocks [B, B+N) the
+// pose gradients (a dependent launch costs ~4 us of drain + dispatch at this size, whatever it computes)
+__global__ __launch_bounds__(64) void step_finalize_kernel(const float* __restrict__ loss_partials, int waves_per_image,
+                                                           double inv_hw, float* __restrict__ sums, int B,
+                                                           const float* __restrict__ pose_partials, int nblk,
+                                                           float* __restrict__ g_pose) {
+    const int i = blockIdx.x;
+    if (i < B) ds::loss_finalize_wave(loss_partials, i, waves_per_image, inv_hw, sums, threadIdx.x);
+    else ds::pose_finalize_wave(pose_partials, i - B, nblk, g_pose, threadIdx.x);
+}
+
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+}  // namespace
 
 extern "C" {
 
@@ -43,6 +62,43 @@ int ds_loss_step_bwd(const float* K, const float* Kinv, const float* pose, const
     if (rc != DS_OK) return rc;
     return ds_warp_bwd(K, Kinv, pose, depth, src, g_warped, B * S, 3, H, W, H, W, g_depth, g_pose, nullptr, workspace,
                        workspace_bytes, stream);
+}
+
+size_t ds_loss_step_fwdbwd_workspace_bytes(int B, int S, int H, int W) {
+    if (B <= 0 || S <= 0 || H < 2 || W < 2) return 0;
+    // both sets of partial sums stay live until the single finalize launch at the end
+    return align256(ds_fused_loss_workspace_bytes(B, H, W)) + ds_warp_bwd_workspace_bytes(B * S, H, W);
+}
+
+int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                        const float* target, const float* g_sums, int B, int S, int H, int W, float* warped,
+                        float* out_loss, float* idt_loss, uint8_t* aux, float* sums, float* g_warped, float* g_depth,
+                        float* g_pose, void* workspace, size_t workspace_bytes, void* stream) {
+    if (B <= 0 || S <= 0 || (long long)B * S > 65535 || H < 2 || W < 2) return DS_ERR_INVALID_ARG;
+    if (!K || !Kinv || !pose || !depth || !src || !target || !warped || !out_loss || !idt_loss || !aux || !sums ||
+        !g_warped || !g_depth || !g_pose)
+        return DS_ERR_INVALID_ARG;
+    if (S > DS_MAX_SOURCES) return DS_ERR_UNSUPPORTED;
+    if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ds_loss_step_fwdbwd_workspace_bytes(B, S, H, W))
+        return DS_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n_loss = align256(ds_fused_loss_workspace_bytes(B, H, W));
+    void* ws_loss = workspace;
+    void* ws_warp = (char*)workspace + n_loss;
+    int rc = ds_warp_fwd(K, Kinv, pose, depth, src, B * S, 3, H, W, H, W, warped, stream);
+    if (rc != DS_OK) return rc;
+    int wpi = 0, nblk = 0;
+    rc = ds::fused_loss_fwd_partials(warped, src, target, B, S, H, W, out_loss, idt_loss, aux, ws_loss, n_loss, &wpi, st);
+    if (rc != DS_OK) return rc;
+    rc = ds_fused_loss_bwd(warped, target, idt_loss, aux, g_sums, B, S, H, W, g_warped, stream);
+    if (rc != DS_OK) return rc;
+    rc = ds::warp_bwd_partials(K, Kinv, pose, depth, src, g_warped, B * S, 3, H, W, H, W, g_depth, nullptr, ws_warp,
+                               workspace_bytes - n_loss, &nblk, st);
+    if (rc != DS_OK) return rc;
+    hipLaunchKernelGGL(step_finalize_kernel, dim3(B + B * S), dim3(64), 0, st, (const float*)ws_loss, wpi,
+                       1.0 / ((double)H * W), sums, B, (const float*)ws_warp, nblk, g_pose);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
 }
 
 }  // extern "C"

@@ -10,6 +10,7 @@
 // users below); the per-function entry points of the reference's unfused call sequence keep the simple form.
 #include "ds_common.h"
 #include "ds_warp_dev.h"
+#include "ds_internal.h"
 #include "depthsynth.h"
 
 using namespace ds;
@@ -635,24 +636,7 @@ __global__ void pose_from_vec_bwd_kernel(const float* __restrict__ vec, const fl
 
 // partials (N, nblk, 12) -> g_pose (N,12): fixed summation order, double accumulator
 __global__ void pose_finalize_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ g_pose) {
-    const int n = blockIdx.x, lane = threadIdx.x;  // one 64-lane wave per pose
-    double a[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) a[i] = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
-        const float* q = partials + ((size_t)n * nblk + b) * 12;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) a[i] += (double)q[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) a[i] += __shfl_xor(a[i], o, 64);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) g_pose[n * 12 + i] = (float)a[i];
-    }
+    pose_finalize_wave(partials, blockIdx.x, nblk, g_pose, threadIdx.x);  // one 64-lane wave per pose
 }
 
 inline int pix_blocks(int HW) { return (HW + kThreads - 1) / kThreads; }
@@ -731,24 +715,12 @@ size_t ds_warp_bwd_workspace_bytes(int N, int H, int W) {
 int ds_warp_bwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
                 const float* g_warped, int N, int C, int Hs, int Ws, int H, int W, float* g_depth, float* g_pose,
                 float* g_src, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!K || !Kinv || !pose || !depth || !src || !g_warped || !g_depth || !g_pose || bad_dims(N, C, Hs, Ws, H, W))
-        return DS_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < ds_warp_bwd_workspace_bytes(N, H, W)) return DS_ERR_WORKSPACE;
-    const WarpGeom G = warp_geom(Hs, Ws, H, W);
-    const int nblk = warp_tiles(H, W, kBwdRows);
-    dim3 g(nblk, N), b(kThreads);
-    float* partials = (float*)workspace;
-    if (C == 3 && g_src)
-        hipLaunchKernelGGL((warp_bwd_kernel<3, true>), g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, g_warped, C,
-                           G, g_depth, g_src, partials);
-    else if (C == 3)
-        hipLaunchKernelGGL(warp_bwd_kernel<3>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, g_warped, C, G,
-                           g_depth, nullptr, partials);
-    else
-        hipLaunchKernelGGL(warp_bwd_kernel<0>, g, b, 0, (hipStream_t)stream, K, Kinv, pose, depth, src, g_warped, C, G,
-                           g_depth, g_src, partials);
-    DS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pose_finalize_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, partials, nblk, g_pose);
+    if (!g_pose) return DS_ERR_INVALID_ARG;
+    int nblk = 0;
+    int rc = ds::warp_bwd_partials(K, Kinv, pose, depth, src, g_warped, N, C, Hs, Ws, H, W, g_depth, g_src, workspace,
+                                   workspace_bytes, &nblk, (hipStream_t)stream);
+    if (rc != DS_OK) return rc;
+    hipLaunchKernelGGL(pose_finalize_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, nblk, g_pose);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }
@@ -784,3 +756,27 @@ int ds_pose_from_vec_bwd(const float* vec, const float* g_pose, int N, float* g_
 }
 
 }  // extern "C"
+
+int ds::warp_bwd_partials(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                          const float* g_warped, int N, int C, int Hs, int Ws, int H, int W, float* g_depth, float* g_src,
+                          void* workspace, size_t workspace_bytes, int* nblk_out, hipStream_t stream) {
+    if (!K || !Kinv || !pose || !depth || !src || !g_warped || !g_depth || bad_dims(N, C, Hs, Ws, H, W))
+        return DS_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < ds_warp_bwd_workspace_bytes(N, H, W)) return DS_ERR_WORKSPACE;
+    const WarpGeom G = warp_geom(Hs, Ws, H, W);
+    const int nblk = warp_tiles(H, W, kBwdRows);
+    dim3 g(nblk, N), b(kThreads);
+    float* partials = (float*)workspace;
+    if (C == 3 && g_src)
+        hipLaunchKernelGGL((warp_bwd_kernel<3, true>), g, b, 0, stream, K, Kinv, pose, depth, src, g_warped, C, G, g_depth,
+                           g_src, partials);
+    else if (C == 3)
+        hipLaunchKernelGGL(warp_bwd_kernel<3>, g, b, 0, stream, K, Kinv, pose, depth, src, g_warped, C, G, g_depth, nullptr,
+                           partials);
+    else
+        hipLaunchKernelGGL(warp_bwd_kernel<0>, g, b, 0, stream, K, Kinv, pose, depth, src, g_warped, C, G, g_depth, g_src,
+                           partials);
+    DS_CHECK_LAUNCH();
+    *nblk_out = nblk;
+    return DS_OK;
+}

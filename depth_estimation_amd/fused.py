@@ -35,7 +35,8 @@ def fused_reprojection_loss(src: torch.Tensor, target: torch.Tensor, depth: torc
     return dict(loss=sums[:, 0], log=sums[:, 1], warped=warped, out_loss=out_loss, idt_loss=idt_loss, aux=aux)
 
 
-def train_step_loss(src, target, depth, pose, K, Kinv, max_depth: float = 80.0, smooth_weight: float = 0.02):
+def train_step_loss(src, target, depth, pose, K, Kinv, max_depth: float = 80.0, smooth_weight: float = 0.02,
+                    eager_grads: bool = False):
     """Summed training loss of train.py:83-89 over the B targets: sum_b [ mean(out/exp(idt+1e-6)) +
     0.02 * regularization_term(depth_b/80, target_b stacked S times) ], as ONE autograd node (ops.train_step).
 
@@ -43,10 +44,14 @@ def train_step_loss(src, target, depth, pose, K, Kinv, max_depth: float = 80.0, 
     summed (train.py:89): every sample has the same pixel count, so the sum of the per-sample means is B x the mean over
     all B*S maps -- one launch instead of B, and the S maps of a target share its edge weights.  The term is linear in
     the depth scale, regularization_term(d / 80) = regularization_term(d) / 80, which saves an elementwise pass over the
-    depth maps and its backward."""
+    depth maps and its backward.
+
+    eager_grads=True forms the depth and pose gradients inside the forward call (ds_loss_step_fwdbwd: all launches of the
+    step back to back, one merged finalize); backward then only scales them by its upstream gradient.  For a training
+    loop that always calls backward (train.py:103) it is the faster form; forward-only callers should leave it off."""
     b = src.shape[0]
     total, sums, reg, warped, out_loss, idt_loss, aux = ops.train_step(K, Kinv, pose, depth, src.detach(), target.detach(),
-                                                                       smooth_weight * b / max_depth)
+                                                                       smooth_weight * b / max_depth, eager_grads)
     return dict(total=total, loss=sums[:, 0], log=sums[:, 1], reg=reg, warped=warped, out_loss=out_loss,
                 idt_loss=idt_loss, aux=aux)
 

@@ -408,10 +408,63 @@ class _TrainStep(torch.autograd.Function):
         return None, None, gp.reshape(ctx.pose_shape), gd, None, None, None
 
 
-def train_step(K, Kinv, pose, depth, src, target, smooth_scale: float):
+class _TrainStepEager(torch.autograd.Function):
+    """The same step with its gradients formed in the forward call: ds_loss_step_fwdbwd (forward and backward launches
+    back to back, one merged finalize) + the smoothness pair.  total is linear in its upstream gradient, so backward only
+    scales the stored gradients by it (loss.backward() passes 1)."""
+
+    @staticmethod
+    def forward(ctx, K, Kinv, pose, depth, src, target, smooth_scale):
+        depth, src, target = L.dev_f32(depth, "depth"), L.dev_f32(src, "src"), L.dev_f32(target, "target")
+        b, s, c, hs, ws = src.shape
+        h, w = target.shape[-2:]
+        n = b * s
+        ctx.pose_shape = pose.shape
+        if c != 3 or target.shape != (b, 3, h, w) or depth.numel() != n * h * w or (hs, ws) != (h, w):
+            raise RuntimeError(f"expected src (B,S,3,H,W), target (B,3,H,W), depth (B,S,1,H,W); got {tuple(src.shape)}, "
+                               f"{tuple(target.shape)}, {tuple(depth.shape)}")
+        K, Kinv, pose = _chk_cam(K, Kinv, pose.reshape(n, 3, 4), n)
+        L.same_device(depth, src, target, K, Kinv, pose)
+        dev, lib, st = src.device, L.lib(), L.stream()
+        f32 = dict(dtype=torch.float32, device=dev)
+        nb = max(lib.ds_loss_step_fwdbwd_workspace_bytes(b, s, h, w), lib.ds_smooth_workspace_bytes(n, h, w))
+        wsb = L.workspace.get(nb, dev)
+        warped, gw = torch.empty(b, s, 3, h, w, **f32), torch.empty(b, s, 3, h, w, **f32)
+        out, idt = torch.empty(b, h, w, **f32), torch.empty(b, h, w, **f32)
+        aux = torch.empty(b, h, w, dtype=torch.uint8, device=dev)
+        sums, reg = torch.empty(b, 2, **f32), torch.empty(1, **f32)
+        gd, gp = torch.empty_like(depth), torch.empty(n, 3, 4, **f32)
+        L.check(lib.ds_loss_step_fwdbwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
+                                        target.data_ptr(), 0, b, s, h, w, warped.data_ptr(), out.data_ptr(), idt.data_ptr(),
+                                        aux.data_ptr(), sums.data_ptr(), gw.data_ptr(), gd.data_ptr(), gp.data_ptr(),
+                                        wsb.data_ptr(), nb, st), "ds_loss_step_fwdbwd")
+        L.check(lib.ds_smooth_batch_fwd(depth.data_ptr(), target.data_ptr(), b, s, 3, h, w, reg.data_ptr(), wsb.data_ptr(), nb,
+                                        st), "ds_smooth_batch_fwd")
+        g_reg = torch.full((1,), smooth_scale, **f32)
+        L.check(lib.ds_smooth_batch_bwd(depth.data_ptr(), target.data_ptr(), g_reg.data_ptr(), b, s, 3, h, w, 1,
+                                        gd.data_ptr(), st), "ds_smooth_batch_bwd")
+        total = sums[:, 0].sum() + smooth_scale * reg[0]
+        ctx.save_for_backward(gd, gp)
+        ctx.mark_non_differentiable(sums, reg, warped, out, idt, aux)
+        ctx.set_materialize_grads(False)
+        return total, sums, reg, warped, out, idt, aux
+
+    @staticmethod
+    def backward(ctx, g_total, *_unused):
+        if g_total is None:
+            return (None,) * 7
+        if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:
+            raise RuntimeError("train_step_loss: gradients w.r.t. the images are not implemented (use "
+                               "fused_reprojection_loss(image_grad=True))")
+        gd, gp = ctx.saved_tensors
+        return None, None, (gp * g_total).reshape(ctx.pose_shape), gd * g_total, None, None, None
+
+
+def train_step(K, Kinv, pose, depth, src, target, smooth_scale: float, eager_grads: bool = False):
     """-> (total, sums (B,2), reg (1), warped, out_loss, idt_loss, aux): total = sum_b sums[b,0] + smooth_scale *
     regularization_term(depth maps, targets), differentiable w.r.t. depth and pose; pose (B*S,3,4) or (B,S,3,4)."""
-    return _TrainStep.apply(K, Kinv, pose, depth, src, target, float(smooth_scale))
+    fn = _TrainStepEager if eager_grads else _TrainStep
+    return fn.apply(K, Kinv, pose, depth, src, target, float(smooth_scale))
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -135,7 +135,7 @@ size_t ds_fused_loss_workspace_bytes(int B, int H, int W);
 int ds_fused_loss_fwd(const float* warped, const float* src, const float* target, int B, int S, int H, int W,
                       float* out_loss, float* idt_loss, uint8_t* aux, float* sums, void* workspace,
                       size_t workspace_bytes, void* stream);
-/* autograd of sums[b][0] w.r.t. warped: g_sums (B) = d(loss)/d(sums[b][0]) -> g_warped (B,S,3,H,W). */
+/* autograd of sums[b][0] w.r.t. warped: g_sums (B) = d(loss)/d(sums[b][0]) (NULL = all ones) -> g_warped (B,S,3,H,W). */
 int ds_fused_loss_bwd(const float* warped, const float* target, const float* idt_loss, const uint8_t* aux,
                       const float* g_sums, int B, int S, int H, int W, float* g_warped, void* stream);
 
@@ -151,6 +151,19 @@ int ds_loss_step_bwd(const float* K, const float* Kinv, const float* pose, const
                      const float* target, const float* warped, const float* idt_loss, const uint8_t* aux,
                      const float* g_sums, int B, int S, int H, int W, float* g_warped, float* g_depth, float* g_pose,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* The whole loss step -- train.py:72-88 for B targets AND its autograd -- in one call: forward and backward launches
+ * back to back on the caller's stream, the two fixed-order finalisations (per-target means, pose gradients) merged into
+ * one launch at the end (five dependent launches instead of six).  The loss of train.py:88 is linear in every
+ * sums[b][0], so the gradients can be formed before the caller's backward runs: g_sums (B) = d(loss)/d(sums[b][0]), or
+ * NULL for a unit upstream gradient -- what loss.backward() passes for the reference's summed loss (train.py:88,103); a
+ * caller with another upstream factor scales g_depth and g_pose by it.  Outputs as in the four calls it replaces;
+ * g_warped (B,S,3,H,W) is scratch.  workspace 16-byte aligned, sized by ds_loss_step_fwdbwd_workspace_bytes. */
+size_t ds_loss_step_fwdbwd_workspace_bytes(int B, int S, int H, int W);
+int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                        const float* target, const float* g_sums, int B, int S, int H, int W, float* warped,
+                        float* out_loss, float* idt_loss, uint8_t* aux, float* sums, float* g_warped, float* g_depth,
+                        float* g_pose, void* workspace, size_t workspace_bytes, void* stream);
 
 /* metrics.regularization_term (metrics.py:75-97): depths (N,1,H,W), targets (N,C,H,W) -> value (1)
  * fp32 on device; workspace from ds_smooth_workspace_bytes. */

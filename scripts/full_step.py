@@ -159,7 +159,7 @@ def hip_path(de, H, W, device):
     return SimpleNamespace(
         construct_pose_batch=lambda vec: de.synthesis.construct_pose_batch(vec, device),
         candidate_depths=lambda src, tgt, pose: de.fused.candidate_depths(src, tgt, pose, Kc, Kcinv, depths, (COST_H, COST_W)),
-        loss=lambda src, tgt, depth, pose: de.fused.train_step_loss(src, tgt, depth, pose, K, Kinv)["total"])
+        loss=lambda src, tgt, depth, pose: de.fused.train_step_loss(src, tgt, depth, pose, K, Kinv, eager_grads=True)["total"])
 
 
 def main(args, rank, local_rank, world):
