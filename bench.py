@@ -304,6 +304,10 @@ def main():
     wl = WORKLOADS[args.workload]
     image_grad = args.image_grad or wl.get("image_grad", False)
     scales = build_problem(de, wl, dev, rank, image_grad, 1)
+    # one ordinary (non-null) stream for everything: torch's default stream is HIP's null stream, whose implicit
+    # synchronisation with every other stream costs several microseconds per launch at this step size
+    main_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(main_stream)
     st = torch.cuda.current_stream().cuda_stream
 
     def step():

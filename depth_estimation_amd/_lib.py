@@ -48,6 +48,8 @@ _SIGNATURES = {
     "ds_fused_loss_workspace_bytes": (_sz, [_i, _i, _i]),
     "ds_fused_loss_fwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "ds_fused_loss_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp]),
+    "ds_fused_loss_fb_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ds_fused_loss_fb": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "ds_loss_step_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ds_loss_step_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "ds_loss_step_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _sz, _fp]),

@@ -56,6 +56,16 @@ __device__ __forceinline__ void pose_finalize_wave(const float* __restrict__ par
 DS_HIDDEN int fused_loss_fwd_partials(const float* warped, const float* src, const float* target, int B, int S, int H, int W,
                                       float* out_loss, float* idt_loss, uint8_t* aux, void* workspace,
                                       size_t workspace_bytes, int* waves_per_image, hipStream_t stream);
+// ds_warp_fwd (C = 3, source size = grid size) and the identity loss map ds_reprojection_loss_fwd(src, target) in ONE launch
+DS_HIDDEN int warp_and_identity(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                                const float* target, int B, int S, int H, int W, float* warped, float* idt_loss,
+                                hipStream_t stream);
+// forward AND backward of the warped groups in one kernel, given the identity map (ds_photo.hip: photo_fb_kernel); S <= 2
+DS_HIDDEN bool fused_loss_fb_supported(int S);
+DS_HIDDEN size_t fused_loss_fb_workspace_bytes(int B, int H, int W);
+DS_HIDDEN int fused_loss_fb_partials(const float* warped, const float* target, const float* idt_loss, const float* g_sums,
+                                     int B, int S, int H, int W, float* out_loss, uint8_t* aux, float* g_warped,
+                                     void* workspace, size_t workspace_bytes, int* waves_per_image, hipStream_t stream);
 // main kernel of ds_warp_bwd; *nblk = pose-gradient partials per image in `workspace`
 DS_HIDDEN int warp_bwd_partials(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
                                 const float* g_warped, int N, int C, int Hs, int Ws, int H, int W, float* g_depth,

@@ -20,6 +20,7 @@
                    // global loads, 2 = no workgroup barriers (wrong results; timing only)
 #endif
 #include "ds_common.h"
+#include "ds_warp_dev.h"
 #include "ds_internal.h"
 #include "depthsynth.h"
 #include <math.h>
@@ -108,17 +109,18 @@ constexpr int kLdsRow = 68;  // 64 columns + left/right halo column (+2 pad)
 // light waves spread evenly over the four SIMDs.
 constexpr int kFwdWaves = 4;
 
+// bid / nblk: this workgroup's index in the list of the launch's loss workgroups (the block index in a plain launch)
 template <int S, bool IDT>
-__global__ __launch_bounds__(64 * kFwdWaves, (IDT ? 2 * S : S) > 4 ? 3 : 4) void photo_fwd_kernel(PhotoFwdParams P) {
+__device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid, int nblk) {
     constexpr int G = IDT ? 2 * S : S;
     constexpr int NP = 1 + G;
     constexpr int kK = G <= 4 ? 4 : 2;  // rows per barrier (slab = 2 * kK * 3 * G * 256 B of LDS)
     __shared__ float lds_x[3][NP][kLdsRow];
     __shared__ float lds_e[2][kK][3][G][64];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int role = (wave + (int)(blockIdx.x >> 3)) & 3;  // 0..2 = channel, 3 = E wave
+    const int role = (wave + (bid >> 3)) & 3;  // 0..2 = channel, 3 = E wave
     const int lane = threadIdx.x & 63;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int wg = xcd_remap(bid, nblk);
     const int bx = wg % P.nbx, t = wg / P.nbx, by = t % P.nby, b = t / P.nby;
     const int H = P.H, W = P.W;
     const int y0 = by * P.RB, yend = min(y0 + P.RB, H);
@@ -292,6 +294,54 @@ __global__ __launch_bounds__(64 * kFwdWaves, (IDT ? 2 * S : S) > 4 ? 3 : 4) void
             cC[p] = nC[p];
             cR[p] = nR[p];
         }
+    }
+}
+
+template <int S, bool IDT>
+__global__ __launch_bounds__(64 * kFwdWaves, (IDT ? 2 * S : S) > 4 ? 3 : 4) void photo_fwd_kernel(PhotoFwdParams P) {
+    photo_fwd_body<S, IDT>(P, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// One launch, two kinds of workgroups: the warp (ds_warp_fwd's tiles: gather-bound, short) and the identity loss
+// (photo_fwd_body on the un-warped sources: VALU-bound, long).  Neither depends on the other -- the identity term
+// knows nothing of depth or pose -- so they can share the compute units instead of running one after the other, and
+// the step has one dependent launch less.  Blocks come in groups of eight (one per XCD, so that a workgroup's XCD is
+// the one its index inside its own list implies).  Measured (gpurun_out/r02_kb3_hetero.txt; two launches = 100 %):
+// B=12 192x640 interleaved in proportion 102 %, warp groups first 97 %, loss groups first 99 %; B=64 320x1024 97.4 % /
+// 100.2 % / 98.1 %.  A launch of a few rounds gains from the missing kernel boundary only (the loss workgroups start
+// while the last warp tiles drain); a long one gains a little from sharing.  So: warp first for small launches,
+// interleaved for large ones.
+struct WarpIdtParams {
+    const float* K; const float* Kinv; const float* pose; const float* depth; const float* src; float* warped;
+    ds::WarpGeom G;
+    int tiles_per_image;   // warp tiles per image
+    int n_warp, n_loss;    // workgroups of each kind
+    int groups_warp, groups_total;
+    int warp_first;        // 1: all warp groups, then all loss groups; 0: interleaved in proportion
+};
+
+template <int S>
+__global__ __launch_bounds__(64 * kFwdWaves, 4) void warp_idt_kernel(WarpIdtParams Q, PhotoFwdParams P) {
+    const int grp = (int)(blockIdx.x >> 3), x = (int)(blockIdx.x & 7);
+    // number of warp groups among the first g groups: floor(g * groups_warp / groups_total)
+    int before, upto;
+    if (Q.warp_first) {
+        before = grp < Q.groups_warp ? grp : Q.groups_warp;
+        upto = grp < Q.groups_warp ? grp + 1 : Q.groups_warp;
+    } else {
+        before = (int)(((long long)grp * Q.groups_warp) / Q.groups_total);
+        upto = (int)(((long long)(grp + 1) * Q.groups_warp) / Q.groups_total);
+    }
+    if (upto > before) {
+        const int t = before * 8 + x;
+        if (t >= Q.n_warp) return;
+        const int n = t / Q.tiles_per_image, tile = t - n * Q.tiles_per_image;
+        warp_fwd_tile<3>(Q.K, Q.Kinv, Q.pose, Q.depth, Q.src, 3, Q.G, Q.warped, n, tile);
+    } else {
+        const int bid = (grp - before) * 8 + x;
+        if (bid >= Q.n_loss) return;   // whole workgroup: no barrier is left waiting
+        photo_fwd_body<S, false>(P, bid, Q.n_loss);
     }
 }
 
@@ -727,6 +777,325 @@ __global__ __launch_bounds__(64 * kWaves, S >= 4 ? 3 : 4) void photo_bwd_kernel(
     }
 }
 
+// =====================================================================================================
+// forward AND backward of the warped groups in one kernel (ds_fused_loss_fb), given the identity map.
+//
+// The backward above recomputes the forward's window sums and its SSIM (60 % of its instructions) because the forward
+// kernel had finished before it started.  Here one workgroup does both for a band of 62 output columns x a row chunk:
+// three channel waves (one colour channel each, all S warped groups) and one light output wave.
+//   * A channel wave runs the forward of its channel exactly like photo_fwd_kernel (rolling sums, neighbours through its
+//     own LDS row), leaves e_c in a double-buffered LDS slab of kK rows and keeps the SSIM intermediates of those rows
+//     in registers;
+//   * after the slab's barrier every channel wave reads all three channels' e_c back, forms E = ((e0+e1)+e2)/3, the min
+//     and argmin over the sources itself (redundantly: ~20 instructions against a second hand-over through LDS), takes
+//     d loss / d out from the identity map, and runs the backward of its channel for those rows: coefficients of the
+//     argmin source, 3x3 spread (horizontally through a second LDS row, vertically over the last two rows), d loss / d
+//     warped for the row above;
+//   * the output wave reads the same slabs, writes out / argmin and the partial sums of the two means.
+// Same arithmetic, in the same order, as photo_fwd_kernel + photo_bwd_kernel: identical results (tests).
+// =====================================================================================================
+struct PhotoFbParams {
+    const float* preds;     // (B, S, 3, H, W) warped
+    const float* target;    // (B, 3, H, W)
+    const float* idt;       // (B, H, W) identity loss map (ds_reprojection_loss_fwd on the un-warped sources)
+    const float* g_sums;    // (B) upstream gradient of mean(out/exp(idt+1e-6)), or NULL = 1
+    int B, H, W, nbx, nby, RB;
+    float inv_hw;
+    float* out;             // (B,H,W)
+    uint8_t* aux;           // (B,H,W)
+    float* wave_partials;   // (nblocks, 2)
+    float* g_preds;         // (B, S, 3, H, W)
+};
+
+template <int S>
+__global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kernel(PhotoFbParams P) {
+    constexpr int NP = 1 + S;  // raw planes of a channel: target, then the S warped groups
+    constexpr int NK = 3 * S;  // masked tap coefficients: (A, B, C) per source
+    constexpr int kK = 2;      // window rows per barrier
+    __shared__ float lds_raw[3][NP][kLdsRow];
+    __shared__ float lds_k[3][NK][kLdsRow];
+    __shared__ float lds_e[2][kK][3][S][64];
+    __shared__ float lds_p[3][kK][NP + 1][64];  // per channel wave: centre values and identity loss of the pending rows
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int role = (wave + (int)(blockIdx.x >> 3)) & 3;  // 0..2 = channel, 3 = output wave
+    const int lane = threadIdx.x & 63;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = wg % P.nbx, tt = wg / P.nbx, by = tt % P.nby, b = tt / P.nby;
+    const int H = P.H, W = P.W;
+    const int y0 = by * P.RB, yend = min(y0 + P.RB, H);
+    const int c0 = bx * 62, col = c0 - 1 + lane;   // lane l holds column c0-1+l; outputs are lanes 1..62
+    const size_t HW = (size_t)H * W;
+    const int nwin = yend - y0 + 2;                // window rows y0-1 .. yend
+    const int nslab = (nwin + kK - 1) / kK;        // every wave of the workgroup joins exactly nslab barriers
+    const bool lane_out = lane >= 1 && lane <= 62 && col < W;
+
+    if (role == 3) {
+        // ---------------------------------------------------------------------------------- output wave
+        const rsrc_t ip = make_rsrc(P.idt + (size_t)b * HW);
+        const unsigned cl = (unsigned)reflect_idx(col, W) * 4u;
+        float sum_ratio = 0.f, sum_out = 0.f;
+        for (int sl = 0; sl < nslab; ++sl) {
+            // identity values of this slab's rows, requested before the wait
+            float iv[kK];
+#pragma unroll
+            for (int k = 0; k < kK; ++k) iv[k] = buf_load_f32(ip, cl, (unsigned)(reflect_idx(y0 - 1 + sl * kK + k, H) * W));
+            __syncthreads();  // the channel waves have filled slab sl & 1
+            const int buf = sl & 1;
+#pragma unroll
+            for (int k = 0; k < kK; ++k) {
+                const int y = y0 - 1 + sl * kK + k;
+                float E[S];
+#pragma unroll
+                for (int g = 0; g < S; ++g)
+                    E[g] = div3((lds_e[buf][k][0][g][lane] + lds_e[buf][k][1][g][lane]) + lds_e[buf][k][2][g][lane]);
+                float best = E[0];
+                int bi = 0;
+#pragma unroll
+                for (int g = 1; g < S; ++g)
+                    if (E[g] < best) { best = E[g]; bi = g; }
+                if (lane_out && y >= y0 && y < yend) {
+                    const size_t o = (size_t)b * HW + (size_t)y * W + col;
+                    P.out[o] = best;
+                    P.aux[o] = (uint8_t)bi;
+                    sum_ratio += best / expf(iv[k] + 1e-6f);  // train.py:88
+                    sum_out += best;                          // train.py:92
+                }
+            }
+        }
+        sum_ratio = wave_sum(sum_ratio);
+        sum_out = wave_sum(sum_out);
+        if (lane == 0) {
+            P.wave_partials[2 * wg + 0] = sum_ratio;
+            P.wave_partials[2 * wg + 1] = sum_out;
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------ channel wave
+    const int c = role;
+    const unsigned uHW = (unsigned)HW;
+    const unsigned cl = (unsigned)reflect_idx(col, W) * 4u;
+    const unsigned ch = (unsigned)reflect_idx(lane < 32 ? c0 - 2 : c0 + 63, W) * 4u;
+    const bool edge = lane == 0 || lane == 63;
+    const int pad_slot = lane == 0 ? 0 : 65;
+    const bool col_exists = col >= 0 && col < W;
+    const float wL = col == 1 ? 2.0f : 1.0f, wR = col == W - 2 ? 2.0f : 1.0f;  // reflect-pad adjoint
+    const rsrc_t tp = make_rsrc(P.target + (size_t)b * 3 * HW);
+    const rsrc_t pp = make_rsrc(P.preds + (size_t)b * (S * 3 * HW));
+    const rsrc_t ip = make_rsrc(P.idt + (size_t)b * HW);
+    const rsrc_t gp = make_rsrc(P.g_preds + (size_t)b * (S * 3 * HW));
+    const float gscale = P.g_sums ? P.g_sums[b] * P.inv_hw : P.inv_hw;
+    float (*lr)[kLdsRow] = lds_raw[c];
+    float (*lk)[kLdsRow] = lds_k[c];
+
+    struct Row { float v[NP], h[NP], iv; };
+    auto issue = [&](int r, Row& o) {
+        const unsigned ro = (unsigned)(reflect_idx(r, H) * W);
+        o.v[0] = buf_load_f32(tp, cl, c * uHW + ro);
+        o.h[0] = buf_load_f32(tp, ch, c * uHW + ro);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            o.v[1 + s] = buf_load_f32(pp, cl, (s * 3 + c) * uHW + ro);
+            o.h[1 + s] = buf_load_f32(pp, ch, (s * 3 + c) * uHW + ro);
+        }
+        o.iv = buf_load_f32(ip, cl, ro);
+    };
+    auto exchange_raw = [&](const Row& o, float (&L)[NP], float (&R)[NP]) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) lr[p][lane + 1] = o.v[p];
+        if (edge) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) lr[p][pad_slot] = o.h[p];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            L[p] = lr[p][lane];
+            R[p] = lr[p][lane + 2];
+        }
+    };
+
+    Roll Sy{0.f, 0.f}, Syy{0.f, 0.f}, Sx[S], Sxx[S], Sxy[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) Sx[s] = Sxx[s] = Sxy[s] = Roll{0.f, 0.f};
+
+    // what a finished window row keeps until its slab's barrier has passed
+    struct Pend {
+        float ax[S], axx[S], axy[S];  // window sums of every source (the SSIM of the argmin source is formed again from
+                                      // them after the barrier: 40 instructions against 2 x 7 more registers, which spill)
+        TgtStats ts;
+    };  // the row's centre values (L1 term, tap values of the output row) and identity loss wait in lds_p: registers are
+        // short (128 with four waves per SIMD), the LDS pipe is not
+    Pend pd[kK];
+    // backward state carried from window row to window row
+    float Hs[2][NK];     // horizontally spread coefficients of window rows j-1 ([0]) and j-2 ([1])
+    float praw[NP];      // centre values, gradient weight and argmin of window row j-1 (= the output row)
+    float pgw = 0.f;
+    int pam = 0;
+#pragma unroll
+    for (int q = 0; q < NK; ++q) Hs[0][q] = Hs[1][q] = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) praw[p] = 0.f;
+
+    Row pend;
+    float cL[NP], cC[NP], cR[NP], civ;
+    float pvC[NP], piv = 0.f;   // centre values / identity loss of the row before the newest one
+#pragma unroll
+    for (int p = 0; p < NP; ++p) pvC[p] = 0.f;
+
+    float ay, ayy, ax[S], axx[S], axy[S];  // sums of the window row a raw row has just finished
+
+    issue(y0 - 2, pend);
+    {
+        float l0[NP], r0[NP];
+        exchange_raw(pend, l0, r0);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { cL[p] = l0[p]; cC[p] = pend.v[p]; cR[p] = r0[p]; }
+        civ = pend.iv;
+    }
+    issue(y0 - 1, pend);
+
+    // One raw row: the neighbours of row r+1 are exchanged and row r+2 requested, the rolling sums take row r (cL, cC, cR),
+    // which finishes the window centred on row r-1 (sums in ay .. axy, centre values in wraw, identity loss in wiv).
+#define DS_FB_RAW_ROW(r_)                                                            \
+    {                                                                                \
+        float nL[NP], nC[NP], nR[NP];                                                \
+        exchange_raw(pend, nL, nR);                                                  \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p) nC[p] = pend.v[p];            \
+        const float niv = pend.iv;                                                   \
+        issue((r_) + 2, pend);                                                       \
+        const float yL = cL[0], yC = cC[0], yR = cR[0];                              \
+        ay = roll(Sy, yL, yC, yR);                                                   \
+        ayy = roll(Syy, yL * yL, yC * yC, yR * yR);                                  \
+        _Pragma("unroll") for (int s = 0; s < S; ++s) {                              \
+            const float xL = cL[1 + s], xC = cC[1 + s], xR = cR[1 + s];              \
+            ax[s] = roll(Sx[s], xL, xC, xR);                                         \
+            axx[s] = roll(Sxx[s], xL * xL, xC * xC, xR * xR);                        \
+            axy[s] = roll(Sxy[s], xL * yL, xC * yC, xR * yR);                        \
+        }                                                                            \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p) {                             \
+            wraw[p] = pvC[p];                                                        \
+            pvC[p] = cC[p];                                                          \
+            cL[p] = nL[p];                                                           \
+            cC[p] = nC[p];                                                           \
+            cR[p] = nR[p];                                                           \
+        }                                                                            \
+        wiv = piv;                                                                   \
+        piv = civ;                                                                   \
+        civ = niv;                                                                   \
+    }
+
+    float wraw[NP], wiv;  // centre values / identity loss of the window row a raw row has just finished
+    // lead-in: rows y0-2 and y0-1 only feed the partial sums
+    DS_FB_RAW_ROW(y0 - 2)
+    DS_FB_RAW_ROW(y0 - 1)
+
+    for (int sl = 0; sl < nslab; ++sl) {
+        const int buf = sl & 1;
+        // ---- forward of kK window rows: j = y0-1 + sl*kK + k, finished by raw row j+1
+#pragma unroll
+        for (int k = 0; k < kK; ++k) {
+            const int j = y0 - 1 + sl * kK + k;
+            DS_FB_RAW_ROW(j + 1)
+            Pend& q = pd[k];
+            target_stats(ay, ayy, q.ts);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                SsimOut so;
+                ssim_from_sums(ax[s], axx[s], axy[s], q.ts, so);
+                q.ax[s] = ax[s]; q.axx[s] = axx[s]; q.axy[s] = axy[s];
+                lds_e[buf][k][c][s][lane] = 0.85f * clamp01(so.v) + 0.15f * fabsf(wraw[0] - wraw[1 + s]);
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) lds_p[c][k][p][lane] = wraw[p];
+            lds_p[c][k][NP][lane] = wiv;
+        }
+        __syncthreads();  // all three channels of these rows are in the slab
+        // ---- backward of the same window rows
+#pragma unroll
+        for (int k = 0; k < kK; ++k) {
+            const int j = y0 - 1 + sl * kK + k;
+            const Pend& q = pd[k];
+            float E[S];
+#pragma unroll
+            for (int g = 0; g < S; ++g)
+                E[g] = div3((lds_e[buf][k][0][g][lane] + lds_e[buf][k][1][g][lane]) + lds_e[buf][k][2][g][lane]);
+            int bi = 0;
+            {
+                float best = E[0];
+#pragma unroll
+                for (int g = 1; g < S; ++g)
+                    if (E[g] < best) { best = E[g]; bi = g; }
+            }
+            // gradient weight of this row's pixels: d loss / d out(p)
+            const float gw = gscale * __builtin_amdgcn_exp2f((lds_p[c][k][NP][lane] + 1e-6f) * -1.4426950408889634f);
+            const bool win_exists = col_exists && j >= 0 && j < H;
+            float bx_ = q.ax[0], bxx = q.axx[0], bxy = q.axy[0];
+#pragma unroll
+            for (int s = 1; s < S; ++s) {
+                const bool is = bi == s;
+                bx_ = is ? q.ax[s] : bx_;
+                bxx = is ? q.axx[s] : bxx;
+                bxy = is ? q.axy[s] : bxy;
+            }
+            SsimOut so;
+            ssim_from_sums(bx_, bxx, bxy, q.ts, so);
+            // clamp passes the gradient iff 0 <= v <= 1
+            const bool live = win_exists && so.v >= 0.0f && so.v <= 1.0f;
+            const Coef kc = ssim_coefs(so, q.ts, live ? gw * (0.85f / 3.0f) : 0.0f);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const bool is = bi == s;
+                lk[3 * s + 0][lane + 1] = is ? kc.A : 0.0f;
+                lk[3 * s + 1][lane + 1] = is ? kc.Bc : 0.0f;
+                lk[3 * s + 2][lane + 1] = is ? kc.Cc : 0.0f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float Hn[NK];
+#pragma unroll
+            for (int t = 0; t < NK; ++t) {
+                const float own = (bi == t / 3) ? (t % 3 == 0 ? kc.A : (t % 3 == 1 ? kc.Bc : kc.Cc)) : 0.0f;
+                Hn[t] = fmaf(wR, lk[t][lane + 2], fmaf(wL, lk[t][lane], own));
+            }
+            // ---- output row t = j-1: windows t-1 (Hs[1]), t (Hs[0]), t+1 (Hn), reflect-pad adjoint weights
+            const int t = j - 1;
+            if (t >= y0 && t < yend) {
+                const float wU = t == 1 ? 2.0f : 1.0f, wD = t == H - 2 ? 2.0f : 1.0f;
+                const float ge = pgw * (1.0f / 3.0f);
+                const float Y = praw[0];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float gA = fmaf(wD, Hn[3 * s + 0], fmaf(wU, Hs[1][3 * s + 0], Hs[0][3 * s + 0]));
+                    const float gB = fmaf(wD, Hn[3 * s + 1], fmaf(wU, Hs[1][3 * s + 1], Hs[0][3 * s + 1]));
+                    const float gC = fmaf(wD, Hn[3 * s + 2], fmaf(wU, Hs[1][3 * s + 2], Hs[0][3 * s + 2]));
+                    const float X = praw[1 + s];
+                    float gg = fmaf(Y, gC, fmaf(X, gB, gA));
+                    const float diff = Y - X;
+                    const float sgn = diff > 0.f ? -1.0f : (diff < 0.f ? 1.0f : 0.0f);
+                    if (pam == s) gg = fmaf(0.15f * ge, sgn, gg);
+                    if (lane_out) buf_store_f32(gg, gp, (unsigned)col * 4u, ((s * 3 + c) * uHW + (unsigned)(t * W)) * 4u);
+                }
+            }
+#pragma unroll
+            for (int t2 = 0; t2 < NK; ++t2) {
+                Hs[1][t2] = Hs[0][t2];
+                Hs[0][t2] = Hn[t2];
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) praw[p] = lds_p[c][k][p][lane];
+            pgw = gw;
+            pam = bi;
+        }
+    }
+#undef DS_FB_RAW_ROW
+}
+
 // ---------------------------------------------------------------------------------------------------
 // SSIM-only backward (autograd of metrics.reprojection_error w.r.t. preds), one plane per "image"
 // ---------------------------------------------------------------------------------------------------
@@ -938,6 +1307,21 @@ inline Geom make_bwd_geom(int B, int H, int W) {
     return g;
 }
 
+// Fused forward+backward kernel: one workgroup per (band of 62 output columns, row chunk); 4 workgroups per CU.
+inline Geom make_fb_geom(int B, int H, int W) {
+    Geom g;
+    g.nbx = (W + 61) / 62;
+    const long long capacity = simd_count();  // workgroups resident at once: four per CU
+    const long long per_chunk = (long long)B * g.nbx;
+    const int max_nby = H / 16 > 1 ? H / 16 : 1;
+    const long long nby = pick_chunks(per_chunk, capacity, max_nby);
+    g.RB = (H + (int)nby - 1) / (int)nby;
+    g.nby = (H + g.RB - 1) / g.RB;
+    g.nblocks = B * g.nbx * g.nby;
+    g.nwaves = g.nblocks;  // one partial-sum slot per workgroup
+    return g;
+}
+
 template <bool FUSED>
 int launch_photo_bwd(int S, const PhotoBwdParams& P, int nblocks, hipStream_t st) {
     dim3 g(nblocks), b(64 * kWaves);
@@ -1048,6 +1432,22 @@ int ds_fused_loss_fwd(const float* warped, const float* src, const float* target
     return DS_OK;
 }
 
+size_t ds_fused_loss_fb_workspace_bytes(int B, int H, int W) { return ds::fused_loss_fb_workspace_bytes(B, H, W); }
+
+int ds_fused_loss_fb(const float* warped, const float* target, const float* idt_loss, const float* g_sums, int B, int S, int H,
+                     int W, float* out_loss, uint8_t* aux, float* sums, float* g_warped, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (!sums) return DS_ERR_INVALID_ARG;
+    int wpi = 0;
+    int rc = ds::fused_loss_fb_partials(warped, target, idt_loss, g_sums, B, S, H, W, out_loss, aux, g_warped, workspace,
+                                        workspace_bytes, &wpi, (hipStream_t)stream);
+    if (rc != DS_OK) return rc;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, wpi,
+                       1.0 / ((double)H * W), sums);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
 int ds_fused_loss_bwd(const float* warped, const float* target, const float* idt_loss, const uint8_t* aux,
                       const float* g_sums, int B, int S, int H, int W, float* g_warped, void* stream) {
     // g_sums may be NULL: unit upstream gradient for every target
@@ -1066,6 +1466,69 @@ int ds_fused_loss_bwd(const float* warped, const float* target, const float* idt
 }
 
 }  // extern "C"
+
+int ds::warp_and_identity(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                          const float* target, int B, int S, int H, int W, float* warped, float* idt_loss,
+                          hipStream_t stream) {
+    if (!K || !Kinv || !pose || !depth || !src || !target || !warped || !idt_loss || bad_dims(B, S, H, W))
+        return DS_ERR_INVALID_ARG;
+    if (S > DS_MAX_SOURCES) return DS_ERR_UNSUPPORTED;
+    const long long HW = (long long)H * W;
+    PhotoFwdParams P{};
+    P.preds = src; P.target = target;
+    P.pred_stride_b = (long long)S * 3 * HW;
+    P.tgt_stride_b = 3 * HW;
+    P.B = B; P.H = H; P.W = W;
+    P.out = idt_loss; P.aux = nullptr;
+    const Geom gm = make_fwd_geom(B, H, W, S, false);
+    P.nbx = gm.nbx; P.nby = gm.nby; P.RB = gm.RB;
+    WarpIdtParams Q{};
+    Q.K = K; Q.Kinv = Kinv; Q.pose = pose; Q.depth = depth; Q.src = src; Q.warped = warped;
+    Q.G = warp_geom(H, W, H, W);
+    const int rows_per_tile = 4 * kFwdRows;
+    Q.tiles_per_image = Q.G.nbx * ((H + rows_per_tile - 1) / rows_per_tile);
+    Q.n_warp = B * S * Q.tiles_per_image;
+    Q.n_loss = gm.nblocks;
+    Q.groups_warp = (Q.n_warp + 7) / 8;
+    Q.groups_total = Q.groups_warp + (Q.n_loss + 7) / 8;
+    Q.warp_first = (long long)Q.n_loss <= 7ll * simd_count() ? 1 : 0;   // fewer than ~4 resident rounds of loss workgroups
+    const dim3 grid(8 * Q.groups_total), block(64 * kFwdWaves);
+    switch (S) {
+        case 1: hipLaunchKernelGGL((warp_idt_kernel<1>), grid, block, 0, stream, Q, P); break;
+        case 2: hipLaunchKernelGGL((warp_idt_kernel<2>), grid, block, 0, stream, Q, P); break;
+        case 3: hipLaunchKernelGGL((warp_idt_kernel<3>), grid, block, 0, stream, Q, P); break;
+        default: hipLaunchKernelGGL((warp_idt_kernel<4>), grid, block, 0, stream, Q, P); break;
+    }
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+bool ds::fused_loss_fb_supported(int S) { return S >= 1 && S <= 2; }
+
+size_t ds::fused_loss_fb_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H < 2 || W < 2) return 0;
+    return (size_t)make_fb_geom(B, H, W).nwaves * 2 * sizeof(float);
+}
+
+int ds::fused_loss_fb_partials(const float* warped, const float* target, const float* idt_loss, const float* g_sums, int B,
+                               int S, int H, int W, float* out_loss, uint8_t* aux, float* g_warped, void* workspace,
+                               size_t workspace_bytes, int* waves_per_image, hipStream_t stream) {
+    if (!warped || !target || !idt_loss || !out_loss || !aux || !g_warped || bad_dims(B, S, H, W)) return DS_ERR_INVALID_ARG;
+    if (!fused_loss_fb_supported(S)) return DS_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < fused_loss_fb_workspace_bytes(B, H, W)) return DS_ERR_WORKSPACE;
+    const Geom g = make_fb_geom(B, H, W);
+    PhotoFbParams P{};
+    P.preds = warped; P.target = target; P.idt = idt_loss; P.g_sums = g_sums;
+    P.B = B; P.H = H; P.W = W; P.nbx = g.nbx; P.nby = g.nby; P.RB = g.RB;
+    P.inv_hw = (float)(1.0 / ((double)H * W));
+    P.out = out_loss; P.aux = aux; P.wave_partials = (float*)workspace; P.g_preds = g_warped;
+    const dim3 grid(g.nblocks), block(64 * kFwdWaves);
+    if (S == 1) hipLaunchKernelGGL((photo_fb_kernel<1>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((photo_fb_kernel<2>), grid, block, 0, stream, P);
+    DS_CHECK_LAUNCH();
+    *waves_per_image = g.nbx * g.nby;
+    return DS_OK;
+}
 
 int ds::fused_loss_fwd_partials(const float* warped, const float* src, const float* target, int B, int S, int H, int W,
                                 float* out_loss, float* idt_loss, uint8_t* aux, void* workspace, size_t workspace_bytes,

@@ -29,6 +29,11 @@ __global__ __launch_bounds__(64) void step_finalize_kernel(const float* __restri
 
 inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
+inline size_t loss_partials_bytes(int B, int H, int W) {  // either form of the loss kernels
+    const size_t a = ds_fused_loss_workspace_bytes(B, H, W), b = ds::fused_loss_fb_workspace_bytes(B, H, W);
+    return align256(a > b ? a : b);
+}
+
 }  // namespace
 
 extern "C" {
@@ -67,7 +72,7 @@ int ds_loss_step_bwd(const float* K, const float* Kinv, const float* pose, const
 size_t ds_loss_step_fwdbwd_workspace_bytes(int B, int S, int H, int W) {
     if (B <= 0 || S <= 0 || H < 2 || W < 2) return 0;
     // both sets of partial sums stay live until the single finalize launch at the end
-    return align256(ds_fused_loss_workspace_bytes(B, H, W)) + ds_warp_bwd_workspace_bytes(B * S, H, W);
+    return loss_partials_bytes(B, H, W) + ds_warp_bwd_workspace_bytes(B * S, H, W);
 }
 
 int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
@@ -82,16 +87,27 @@ int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, co
     if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ds_loss_step_fwdbwd_workspace_bytes(B, S, H, W))
         return DS_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const size_t n_loss = align256(ds_fused_loss_workspace_bytes(B, H, W));
+    const size_t n_loss = loss_partials_bytes(B, H, W);
     void* ws_loss = workspace;
     void* ws_warp = (char*)workspace + n_loss;
-    int rc = ds_warp_fwd(K, Kinv, pose, depth, src, B * S, 3, H, W, H, W, warped, stream);
-    if (rc != DS_OK) return rc;
-    int wpi = 0, nblk = 0;
-    rc = ds::fused_loss_fwd_partials(warped, src, target, B, S, H, W, out_loss, idt_loss, aux, ws_loss, n_loss, &wpi, st);
-    if (rc != DS_OK) return rc;
-    rc = ds_fused_loss_bwd(warped, target, idt_loss, aux, g_sums, B, S, H, W, g_warped, stream);
-    if (rc != DS_OK) return rc;
+    int rc, wpi = 0, nblk = 0;
+    if (ds::fused_loss_fb_supported(S)) {
+        // the warp and the identity map (un-warped sources against the target: nothing of it depends on depth or pose)
+        // share one launch; then the forward and the backward of the warped groups in ONE kernel: the backward's window
+        // sums are the forward's
+        rc = ds::warp_and_identity(K, Kinv, pose, depth, src, target, B, S, H, W, warped, idt_loss, st);
+        if (rc != DS_OK) return rc;
+        rc = ds::fused_loss_fb_partials(warped, target, idt_loss, g_sums, B, S, H, W, out_loss, aux, g_warped, ws_loss, n_loss,
+                                        &wpi, st);
+        if (rc != DS_OK) return rc;
+    } else {
+        rc = ds_warp_fwd(K, Kinv, pose, depth, src, B * S, 3, H, W, H, W, warped, stream);
+        if (rc != DS_OK) return rc;
+        rc = ds::fused_loss_fwd_partials(warped, src, target, B, S, H, W, out_loss, idt_loss, aux, ws_loss, n_loss, &wpi, st);
+        if (rc != DS_OK) return rc;
+        rc = ds_fused_loss_bwd(warped, target, idt_loss, aux, g_sums, B, S, H, W, g_warped, stream);
+        if (rc != DS_OK) return rc;
+    }
     rc = ds::warp_bwd_partials(K, Kinv, pose, depth, src, g_warped, B * S, 3, H, W, H, W, g_depth, nullptr, ws_warp,
                                workspace_bytes - n_loss, &nblk, st);
     if (rc != DS_OK) return rc;

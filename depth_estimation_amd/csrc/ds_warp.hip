@@ -119,80 +119,13 @@ __global__ __launch_bounds__(kThreads) void grid_sample_bwd_kernel(const float* 
 //   * the divisions of the forward projection share one refined reciprocal per denominator (u = q0/z, v = q1/z) or
 //     take it from the host (division by Ws-1, Hs-1): 5 instructions per correctly rounded quotient instead of 12;
 //   * the border cases of the bilinear gather select WEIGHTS once per pixel, not texel values once per channel.
-#ifndef DS_FWD_ROWS
-#define DS_FWD_ROWS 4
-#endif
-constexpr int kFwdRows = DS_FWD_ROWS;  // rows per wave: kFwdRows depth loads, then kFwdRows x C x 2 corner-pair gathers in flight
-
 template <int C>
 __global__ __launch_bounds__(kThreads) void warp_fwd_kernel(const float* __restrict__ K, const float* __restrict__ Kinv,
                                                             const float* __restrict__ pose,
                                                             const float* __restrict__ depth,
                                                             const float* __restrict__ src, int Cdyn, WarpGeom G,
                                                             float* __restrict__ warped) {
-    const int n = blockIdx.y;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int bx = blockIdx.x % G.nbx, by = blockIdx.x / G.nbx;
-    const int yb = (by * (kThreads / 64) + wave) * kFwdRows;
-    if (yb >= G.H) return;
-    const int x = bx * 64 + lane, xc = min(x, G.W - 1);
-    const int Cc = C > 0 ? C : Cdyn;
-    const unsigned HW = (unsigned)(G.H * G.W), HsWs = (unsigned)(G.Hs * G.Ws);
-    Cam cam;
-    load_cam(cam, K, Kinv, pose + 12 * n);
-    const rsrc_t dp = make_rsrc(depth + (size_t)n * HW);
-    const rsrc_t sp = make_rsrc(src + (size_t)n * Cc * HsWs);
-    const rsrc_t op = make_rsrc(warped + (size_t)n * Cc * HW);
-    const unsigned xb = (unsigned)xc * 4u;
-    float d[kFwdRows];
-#pragma unroll
-    for (int i = 0; i < kFwdRows; ++i) d[i] = buf_load_f32(dp, xb, (unsigned)(min(yb + i, G.H - 1) * G.W));
-    Tap t[kFwdRows];
-#pragma unroll
-    for (int i = 0; i < kFwdRows; ++i) {
-        Proj pr;
-        float rz;
-        project_pixel_lean(cam, (float)xc, (float)min(yb + i, G.H - 1), d[i], pr, rz);
-        make_tap(pr.u, pr.v, G, t[i]);
-    }
-    if (C > 0) {
-        float2_t top[kFwdRows][C > 0 ? C : 1], bot[kFwdRows][C > 0 ? C : 1];
-#pragma unroll
-        for (int i = 0; i < kFwdRows; ++i)
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                top[i][c] = buf_load_f32x2(sp, t[i].o_top, c * HsWs * 4u);
-                bot[i][c] = buf_load_f32x2(sp, t[i].o_bot, c * HsWs * 4u);
-            }
-#pragma unroll
-        for (int i = 0; i < kFwdRows; ++i) {
-            if (x < G.W && yb + i < G.H) {
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    float acc = top[i][c].x * t[i].wa_t;
-                    acc = fmaf(top[i][c].y, t[i].wb_t, acc);
-                    acc = fmaf(bot[i][c].x, t[i].wa_b, acc);
-                    acc = fmaf(bot[i][c].y, t[i].wb_b, acc);
-                    buf_store_f32(acc, op, (unsigned)x * 4u, (c * HW + (unsigned)((yb + i) * G.W)) * 4u);
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < kFwdRows; ++i) {
-            if (x < G.W && yb + i < G.H) {
-                for (int c = 0; c < Cc; ++c) {
-                    const float2_t tp = buf_load_f32x2(sp, t[i].o_top, c * HsWs * 4u);
-                    const float2_t bt = buf_load_f32x2(sp, t[i].o_bot, c * HsWs * 4u);
-                    float acc = tp.x * t[i].wa_t;
-                    acc = fmaf(tp.y, t[i].wb_t, acc);
-                    acc = fmaf(bt.x, t[i].wa_b, acc);
-                    acc = fmaf(bt.y, t[i].wb_b, acc);
-                    buf_store_f32(acc, op, (unsigned)x * 4u, (c * HW + (unsigned)((yb + i) * G.W)) * 4u);
-                }
-            }
-        }
-    }
+    warp_fwd_tile<C>(K, Kinv, pose, depth, src, Cdyn, G, warped, blockIdx.y, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------

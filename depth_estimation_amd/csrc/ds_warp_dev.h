@@ -84,6 +84,82 @@ __device__ __forceinline__ void project_pixel_lean(const Cam& cam, float fx, flo
     o.v = div_by(o.q[1], o.z, rz);
 }
 
+#ifndef DS_FWD_ROWS
+#define DS_FWD_ROWS 4
+#endif
+constexpr int kFwdRows = DS_FWD_ROWS;  // rows per wave: kFwdRows depth loads, then kFwdRows x C x 2 corner-pair gathers in flight
+
+// One tile of ds_warp_fwd: image n, tile index `tile` (64 columns x 4 waves x kFwdRows rows), 256 threads.  A device
+// function so that the forward loss step can run these tiles next to other work in one launch (ds_photo.hip).
+template <int C>
+__device__ __forceinline__ void warp_fwd_tile(const float* __restrict__ K, const float* __restrict__ Kinv,
+                                              const float* __restrict__ pose, const float* __restrict__ depth,
+                                              const float* __restrict__ src, int Cdyn, const WarpGeom& G,
+                                              float* __restrict__ warped, int n, int tile) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int bx = tile % G.nbx, by = tile / G.nbx;
+    const int yb = (by * 4 + wave) * kFwdRows;
+    if (yb >= G.H) return;
+    const int x = bx * 64 + lane, xc = min(x, G.W - 1);
+    const int Cc = C > 0 ? C : Cdyn;
+    const unsigned HW = (unsigned)(G.H * G.W), HsWs = (unsigned)(G.Hs * G.Ws);
+    Cam cam;
+    load_cam(cam, K, Kinv, pose + 12 * n);
+    const rsrc_t dp = make_rsrc(depth + (size_t)n * HW);
+    const rsrc_t sp = make_rsrc(src + (size_t)n * Cc * HsWs);
+    const rsrc_t op = make_rsrc(warped + (size_t)n * Cc * HW);
+    const unsigned xb = (unsigned)xc * 4u;
+    float d[kFwdRows];
+#pragma unroll
+    for (int i = 0; i < kFwdRows; ++i) d[i] = buf_load_f32(dp, xb, (unsigned)(min(yb + i, G.H - 1) * G.W));
+    Tap t[kFwdRows];
+#pragma unroll
+    for (int i = 0; i < kFwdRows; ++i) {
+        Proj pr;
+        float rz;
+        project_pixel_lean(cam, (float)xc, (float)min(yb + i, G.H - 1), d[i], pr, rz);
+        make_tap(pr.u, pr.v, G, t[i]);
+    }
+    if (C > 0) {
+        float2_t top[kFwdRows][C > 0 ? C : 1], bot[kFwdRows][C > 0 ? C : 1];
+#pragma unroll
+        for (int i = 0; i < kFwdRows; ++i)
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                top[i][c] = buf_load_f32x2(sp, t[i].o_top, c * HsWs * 4u);
+                bot[i][c] = buf_load_f32x2(sp, t[i].o_bot, c * HsWs * 4u);
+            }
+#pragma unroll
+        for (int i = 0; i < kFwdRows; ++i) {
+            if (x < G.W && yb + i < G.H) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float acc = top[i][c].x * t[i].wa_t;
+                    acc = fmaf(top[i][c].y, t[i].wb_t, acc);
+                    acc = fmaf(bot[i][c].x, t[i].wa_b, acc);
+                    acc = fmaf(bot[i][c].y, t[i].wb_b, acc);
+                    buf_store_f32(acc, op, (unsigned)x * 4u, (c * HW + (unsigned)((yb + i) * G.W)) * 4u);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kFwdRows; ++i) {
+            if (x < G.W && yb + i < G.H) {
+                for (int c = 0; c < Cc; ++c) {
+                    const float2_t tp = buf_load_f32x2(sp, t[i].o_top, c * HsWs * 4u);
+                    const float2_t bt = buf_load_f32x2(sp, t[i].o_bot, c * HsWs * 4u);
+                    float acc = tp.x * t[i].wa_t;
+                    acc = fmaf(tp.y, t[i].wb_t, acc);
+                    acc = fmaf(bt.x, t[i].wa_b, acc);
+                    acc = fmaf(bt.y, t[i].wb_b, acc);
+                    buf_store_f32(acc, op, (unsigned)x * 4u, (c * HW + (unsigned)((yb + i) * G.W)) * 4u);
+                }
+            }
+        }
+    }
+}
+
 // host side of WarpGeom
 inline WarpGeom warp_geom(int Hs, int Ws, int H, int W) {
     WarpGeom G;

@@ -139,6 +139,15 @@ int ds_fused_loss_fwd(const float* warped, const float* src, const float* target
 int ds_fused_loss_bwd(const float* warped, const float* target, const float* idt_loss, const uint8_t* aux,
                       const float* g_sums, int B, int S, int H, int W, float* g_warped, void* stream);
 
+/* Forward and backward of the warped groups in ONE kernel, given the identity map idt_loss (B,H,W) =
+ * ds_reprojection_loss_fwd(src, target): out_loss, aux, sums as ds_fused_loss_fwd, g_warped as ds_fused_loss_bwd (g_sums
+ * (B) or NULL = ones), bit for bit, without the backward's recomputation of the forward's window sums.  S <= 2
+ * (DS_ERR_UNSUPPORTED beyond: use the pair above). */
+size_t ds_fused_loss_fb_workspace_bytes(int B, int H, int W);
+int ds_fused_loss_fb(const float* warped, const float* target, const float* idt_loss, const float* g_sums, int B, int S, int H,
+                     int W, float* out_loss, uint8_t* aux, float* sums, float* g_warped, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* The two halves of a loss step in one call each, on the caller's stream: ds_warp_fwd + ds_fused_loss_fwd, and
  * ds_fused_loss_bwd + ds_warp_bwd (train.py:72-88 and its autograd for B targets; source and grid sizes equal).
  * Arguments as in the four calls; g_warped (B,S,3,H,W) is scratch for the backward.  Same launches, half the calls for a

@@ -173,6 +173,16 @@ int main(int argc, char** argv) {
             });
             printf("   ds_loss_step_fwdbwd (one call, merged finalize): %.4f ms per step = %.2f Gpix/s\n", one, (double)N * HW / one / 1e6);
         }
+        typedef int (*fb_t)(const float*, const float*, const float*, const float*, int, int, int, int, float*, uint8_t*, float*, float*, void*, size_t, void*);
+        if (auto fb = (fb_t)dlsym(h, "ds_fused_loss_fb")) {
+            auto fbws = (ws3_t)dlsym(h, "ds_fused_loss_fb_workspace_bytes");
+            size_t n4 = fbws(B, H, W); void* w4; CK(hipMalloc(&w4, n4 ? n4 : 4));
+            double t_fb = wall([&] { fb(warped, tgt, idt, nullptr, B, S, H, W, out, aux, sums, g_warped, w4, n4, s1); });
+            double t_fwd = wall([&] { loss_fwd(warped, src, tgt, B, S, H, W, out, idt, aux, sums, w1, n1, s1); });
+            double t_bwd = wall([&] { loss_bwd(warped, tgt, idt, aux, g_sums, B, S, H, W, g_warped, s1); });
+            double t_wb = wall([&] { warp_bwd(K, Kinv, pose, depth, src, g_warped, N, 3, H, W, H, W, g_depth, g_pose, g_src, w2, n2, s1); });
+            printf("   wall clock, each alone back to back: fused_loss_fb %.4f (+finalize), fused_loss_fwd %.4f (+finalize), fused_loss_bwd %.4f, warp_bwd %.4f (+finalize) ms\n", t_fb, t_fwd, t_bwd, t_wb);
+        }
         printf("   wall clock, back to back: warp_fwd %.4f, identity loss %.4f, both sequential %.4f, on two streams %.4f; whole step %.4f ms\n",
                w_only, i_only, seq, conc, full);
     }

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round profile: bench lines + rocprofv3 kernel stats + HBM-traffic PMC passes, everything under gpurun_out/<tag>/
-#   scripts/profile_round.sh <tag>
+# Round profile: bench lines + rocprofv3 kernel stats + PMC passes (HBM traffic, SQ), everything under gpurun_out/<tag>/
+#   scripts/profile_round.sh <tag> [quick]
 set -u
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -10,11 +10,14 @@ python3 -c "import torch" || exit 1
 timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 > $out/bench_b12.json 2> $out/bench_b12.err || exit 1
 timeout -k 10 300 python3 bench.py --steps 50 --warmup 10 --workload b64_s2_320x1024_fwdbwd --no-cpu > $out/bench_hires.json 2> $out/bench_hires.err || exit 1
 timeout -k 10 300 python3 bench.py --steps 100 --warmup 10 --workload b12_s2_192x640_pyramid4_fwdbwd --no-cpu > $out/bench_pyramid.json 2> $out/bench_pyramid.err || exit 1
-timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $out/stats_b12 -o p --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu --streams 1 > $out/stats_b12.log 2>&1 || exit 1
-timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $out/stats_hires -o p --output-format csv -- python3 bench.py --steps 20 --warmup 5 --workload b64_s2_320x1024_fwdbwd --no-cpu --streams 1 > $out/stats_hires.log 2>&1 || exit 1
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $out/stats_b12 -o p --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu --cold-steps 0 --pipelined 0 > $out/stats_b12.log 2>&1 || exit 1
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $out/stats_hires -o p --output-format csv -- python3 bench.py --steps 20 --warmup 5 --workload b64_s2_320x1024_fwdbwd --no-cpu --cold-steps 0 --pipelined 0 > $out/stats_hires.log 2>&1 || exit 1
+[ "${2:-}" = quick ] && { echo done-quick; exit 0; }
 for wl in b12_s2_192x640_fwdbwd b64_s2_320x1024_fwdbwd; do
   for c in FETCH_SIZE WRITE_SIZE; do
     scripts/pmc_pass.sh ${tag}_${c}_${wl} $wl $c || exit 1
   done
+  scripts/pmc_pass.sh ${tag}_SQ1_${wl} $wl SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY || exit 1
+  scripts/pmc_pass.sh ${tag}_SQ2_${wl} $wl SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 || exit 1
 done
 echo done
