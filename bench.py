@@ -87,7 +87,10 @@ class Scale:
         self.ws_warp = torch.empty(self.ws_warp_n, dtype=torch.uint8, device=dev)
         p = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
         lib, N = self.lib, self.N
-        self.names = ("warp_fwd", "loss_fwd", "loss_bwd", "warp_bwd") + (("metrics",) if metrics else ())
+        # The launches of a step, individually callable (per-kernel timing).  Without the image gradient and with S <= 2
+        # the step is what ds_loss_step_fwdbwd launches: warp + identity map in one launch, forward+backward of the warped
+        # groups in one kernel, warp backward; otherwise the four classic calls.
+        self.fused_path = (not image_grad) and S <= 2
         if metrics:
             # test.py:73-81 on the first source's depth map; ground truth U(1,80) with 30 % invalid (zero) pixels
             self.gt = (1 + 79 * torch.rand(B, 1, H, W, generator=g)).to(dev)
@@ -96,18 +99,46 @@ class Scale:
             self.met = torch.empty(8, **f)
             self.ws_met_n = self.lib.ds_metrics_workspace_bytes(B, H, W)
             self.ws_met = torch.empty(self.ws_met_n, dtype=torch.uint8, device=dev)
-        self.calls = {
-            "warp_fwd": lambda st: lib.ds_warp_fwd(p(self.K), p(self.Kinv), p(self.pose), p(self.depth), p(self.src), N, 3,
-                                                    H, W, H, W, p(self.warped), st),
-            "loss_fwd": lambda st: lib.ds_fused_loss_fwd(p(self.warped), p(self.src), p(self.tgt), B, S, H, W, p(self.out),
-                                                         p(self.idt), p(self.aux), p(self.sums), p(self.ws_loss),
-                                                         self.ws_loss_n, st),
-            "loss_bwd": lambda st: lib.ds_fused_loss_bwd(p(self.warped), p(self.tgt), p(self.idt), p(self.aux),
-                                                         p(self.g_sums), B, S, H, W, p(self.g_warped), st),
-            "warp_bwd": lambda st: lib.ds_warp_bwd(p(self.K), p(self.Kinv), p(self.pose), p(self.depth), p(self.src),
-                                                   p(self.g_warped), N, 3, H, W, H, W, p(self.g_depth), p(self.g_pose),
-                                                   p(self.g_src), p(self.ws_warp), self.ws_warp_n, st),
-        }
+        self.ws_fb_n = self.lib.ds_fused_loss_fb_workspace_bytes(B, H, W)
+        self.ws_fb = torch.empty(max(self.ws_fb_n, 16), dtype=torch.uint8, device=dev)
+        px, tp = self.N * H * W, B * H * W
+        warp_bwd = lambda st: lib.ds_warp_bwd(p(self.K), p(self.Kinv), p(self.pose), p(self.depth), p(self.src),  # noqa: E731
+                                              p(self.g_warped), N, 3, H, W, H, W, p(self.g_depth), p(self.g_pose),
+                                              p(self.g_src), p(self.ws_warp), self.ws_warp_n, st)
+        # algorithmic HBM bytes of each call: every input read once, every output written once (DESIGN.md 4)
+        if self.fused_path:
+            self.calls = {
+                "warp_identity": lambda st: lib.ds_warp_identity_fwd(p(self.K), p(self.Kinv), p(self.pose), p(self.depth),
+                                                                     p(self.src), p(self.tgt), B, S, H, W, p(self.warped),
+                                                                     p(self.idt), st),
+                "loss_fb": lambda st: lib.ds_fused_loss_fb(p(self.warped), p(self.tgt), p(self.idt), 0, B, S, H, W, p(self.out),
+                                                           p(self.aux), p(self.sums), p(self.g_warped), p(self.ws_fb),
+                                                           self.ws_fb_n, st),
+                "warp_bwd": warp_bwd,
+            }
+            self.alg_bytes = {
+                "warp_identity": px * (4 + 12 + 12) + tp * (12 + 4),   # depth + src -> warped; + target -> idt
+                "loss_fb": px * (12 + 12) + tp * (12 + 4 + 4 + 1),     # warped + target + idt -> g_warped, out, aux
+                "warp_bwd": px * (4 + 12 + 12 + 4),                    # depth + src + g_warped -> g_depth
+            }
+        else:
+            self.calls = {
+                "warp_fwd": lambda st: lib.ds_warp_fwd(p(self.K), p(self.Kinv), p(self.pose), p(self.depth), p(self.src), N, 3,
+                                                        H, W, H, W, p(self.warped), st),
+                "loss_fwd": lambda st: lib.ds_fused_loss_fwd(p(self.warped), p(self.src), p(self.tgt), B, S, H, W, p(self.out),
+                                                             p(self.idt), p(self.aux), p(self.sums), p(self.ws_loss),
+                                                             self.ws_loss_n, st),
+                "loss_bwd": lambda st: lib.ds_fused_loss_bwd(p(self.warped), p(self.tgt), p(self.idt), p(self.aux),
+                                                             p(self.g_sums), B, S, H, W, p(self.g_warped), st),
+                "warp_bwd": warp_bwd,
+            }
+            self.alg_bytes = {
+                "warp_fwd": px * (4 + 12 + 12),                       # depth + src (gather) -> warped
+                "loss_fwd": px * (12 + 12) + tp * (12 + 4 + 4 + 1),   # warped + src + target -> out, idt, aux
+                "loss_bwd": px * (12 + 12) + tp * (12 + 4 + 1),       # warped + target + idt + aux -> g_warped
+                "warp_bwd": px * (4 + 12 + 12 + 4 + (12 if image_grad else 0)),  # depth + src + g_warped -> g_depth [+ g_src]
+            }
+        self.names = tuple(self.calls) + (("metrics",) if metrics else ())
         # the step as ONE call (forward + backward launches and a single merged finalize); the image-gradient scatter is
         # only in the four-call form
         self.ws_step_n = self.lib.ds_loss_step_fwdbwd_workspace_bytes(B, S, H, W)
@@ -119,15 +150,6 @@ class Scale:
         if metrics:
             self.calls["metrics"] = lambda st: lib.ds_depth_metrics(p(self.pred), p(self.gt), B, H, W, p(self.met), 0,
                                                                     p(self.ws_met), self.ws_met_n, st)
-        # algorithmic HBM bytes of each call: every input read once, every output written once (DESIGN.md 4)
-        px, tp = self.N * H * W, B * H * W
-        self.alg_bytes = {
-            "warp_fwd": px * (4 + 12 + 12),                       # depth + src (gather) -> warped
-            "loss_fwd": px * (12 + 12) + tp * (12 + 4 + 4 + 1),   # warped + src + target -> out, idt, aux
-            "loss_bwd": px * (12 + 12) + tp * (12 + 4 + 1),       # warped + target + idt + aux -> g_warped
-            "warp_bwd": px * (4 + 12 + 12 + 4 + (12 if image_grad else 0)),  # depth + src + g_warped -> g_depth [+ g_src]
-        }
-        if metrics:
             self.alg_bytes["metrics"] = tp * 8                    # pred + gt
         # what BASELINE.md prices the step with: SURVEY 8d's bytes of the fused path (no warped / g_warped round trips)
         self.step_bytes = tp * step_alg_bytes_per_target_px(S, 3, image_grad) + (tp * 8 if metrics else 0)

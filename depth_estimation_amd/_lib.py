@@ -48,6 +48,7 @@ _SIGNATURES = {
     "ds_fused_loss_workspace_bytes": (_sz, [_i, _i, _i]),
     "ds_fused_loss_fwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "ds_fused_loss_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp]),
+    "ds_warp_identity_fwd": (_i, [_fp] * 6 + [_i] * 4 + [_fp, _fp, _fp]),
     "ds_fused_loss_fb_workspace_bytes": (_sz, [_i, _i, _i]),
     "ds_fused_loss_fb": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "ds_loss_step_workspace_bytes": (_sz, [_i, _i, _i, _i]),
@@ -61,6 +62,8 @@ _SIGNATURES = {
     "ds_smooth_batch_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _sz, _fp]),
     "ds_smooth_batch_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp]),
     "ds_ingest_u8": (_i, [_fp, _i, _i, _i, _fp, _fp]),
+    "ds_ingest_resize_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ds_ingest_resize_u8": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _sz, _fp]),
     "ds_metrics_workspace_bytes": (_sz, [_i, _i, _i]),
     "ds_depth_metrics": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _fp, _sz, _fp]),
     "ds_depth_metrics_noalloc": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _fp]),

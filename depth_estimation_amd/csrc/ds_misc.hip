@@ -648,6 +648,120 @@ __global__ __launch_bounds__(kThreads) void ingest_u8_kernel(const uint8_t* __re
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The resize of the loaders on the device (dataset.py:51,110: tf.resize(img, (192, 640)) on a PIL image = PIL's
+// Image.resize(BILINEAR)).  The arithmetic is Pillow's (libImaging/Resample.c): a separable triangle filter whose support
+// grows with the down-scale factor, coefficients normalised in double and rounded to 22-bit fixed point, each pass
+// accumulated in int32 from 1 << 21 and clipped to 0..255, horizontal pass first with its result rounded to uint8.
+// Integer work, so bit-exact: the coefficients are formed on the device in IEEE double with Pillow's operation order
+// (this file is compiled without contraction), one thread per output column / row.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kPilBits = 32 - 8 - 2;
+constexpr int kPilMaxTaps = 64;  // down-scaling by up to ~31x
+
+struct PilAxis { int in_size, out_size, ksize; double scale, filterscale, support, ss; };
+
+inline bool pil_axis(PilAxis& a, int in_size, int out_size) {
+    a.in_size = in_size; a.out_size = out_size;
+    a.scale = (double)in_size / out_size;
+    a.filterscale = a.scale < 1.0 ? 1.0 : a.scale;
+    a.support = 1.0 * a.filterscale;
+    a.ss = 1.0 / a.filterscale;
+    a.ksize = (int)ceil(a.support) * 2 + 1;
+    return a.ksize <= kPilMaxTaps;
+}
+
+// fixed-point coefficients of output sample xx: first tap and tap count; kk[i * stride] receives tap i
+__device__ __forceinline__ int pil_coeffs(const PilAxis& a, int xx, int& xmin_out, int* kk, int stride) {
+    const double center = (xx + 0.5) * a.scale;
+    int xmin = (int)(center - a.support + 0.5), xmax = (int)(center + a.support + 0.5);
+    if (xmin < 0) xmin = 0;
+    if (xmax > a.in_size) xmax = a.in_size;
+    xmax -= xmin;
+    if (xmax > a.ksize) xmax = a.ksize;
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) {
+        double t = (x + xmin - center + 0.5) * a.ss;
+        if (t < 0.0) t = -t;
+        ww += t < 1.0 ? 1.0 - t : 0.0;
+    }
+    for (int x = 0; x < xmax; ++x) {
+        double t = (x + xmin - center + 0.5) * a.ss;
+        if (t < 0.0) t = -t;
+        const double w = t < 1.0 ? 1.0 - t : 0.0;
+        const double k = ww != 0.0 ? w / ww : w;
+        kk[x * stride] = k < 0 ? (int)(-0.5 + k * (double)(1 << kPilBits)) : (int)(0.5 + k * (double)(1 << kPilBits));
+    }
+    xmin_out = xmin;
+    return xmax;
+}
+
+__device__ __forceinline__ int pil_clip8(int v) {
+    v >>= kPilBits;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// horizontal pass: in (N,Hin,Win,3) -> tmp (N,Hin,Wout,3).  A block owns 64 output columns (their coefficients in LDS,
+// computed once) and walks down the rows four at a time.
+__global__ __launch_bounds__(kThreads) void pil_resize_h_kernel(const uint8_t* __restrict__ in, PilAxis A, int Hin,
+                                                                int rows_per_block, uint8_t* __restrict__ tmp) {
+    __shared__ int kk[kPilMaxTaps][64];
+    __shared__ int first[64], count[64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int xx = blockIdx.x * 64 + tx, n = blockIdx.z;
+    if (ty == 0) {
+        int xmin = 0, cnt = 0;
+        if (xx < A.out_size) cnt = pil_coeffs(A, xx, xmin, &kk[0][tx], 64);
+        first[tx] = xmin;
+        count[tx] = cnt;
+    }
+    __syncthreads();
+    if (xx >= A.out_size) return;
+    const int xmin = first[tx], cnt = count[tx];
+    const int y_end = min(Hin, (int)(blockIdx.y + 1) * rows_per_block);
+    for (int y = blockIdx.y * rows_per_block + ty; y < y_end; y += 4) {
+        const uint8_t* row = in + ((size_t)n * Hin + y) * A.in_size * 3 + (size_t)xmin * 3;
+        int a0 = 1 << (kPilBits - 1), a1 = a0, a2 = a0;
+        for (int x = 0; x < cnt; ++x) {
+            const int k = kk[x][tx];
+            a0 += (int)row[3 * x + 0] * k;
+            a1 += (int)row[3 * x + 1] * k;
+            a2 += (int)row[3 * x + 2] * k;
+        }
+        uint8_t* o = tmp + (((size_t)n * Hin + y) * A.out_size + xx) * 3;
+        o[0] = (uint8_t)pil_clip8(a0);
+        o[1] = (uint8_t)pil_clip8(a1);
+        o[2] = (uint8_t)pil_clip8(a2);
+    }
+}
+
+// vertical pass: tmp (N,Hin,Wout,3) -> out_u8 (N,Hout,Wout,3) and / or out_f32 (N,3,Hout,Wout) = value / 255 (to_tensor).
+// One output row per blockIdx.y (its coefficients are the same for every thread), one interleaved byte per thread.
+__global__ __launch_bounds__(kThreads) void pil_resize_v_kernel(const uint8_t* __restrict__ tmp, PilAxis A, int Wout,
+                                                                uint8_t* __restrict__ out_u8, float* __restrict__ out_f32) {
+    __shared__ int kk[kPilMaxTaps];
+    __shared__ int first, count;
+    const int yy = blockIdx.y, n = blockIdx.z;
+    if (threadIdx.x == 0) {
+        int ymin = 0;
+        count = pil_coeffs(A, yy, ymin, kk, 1);
+        first = ymin;
+    }
+    __syncthreads();
+    const int xc = blockIdx.x * kThreads + threadIdx.x;  // interleaved (x, channel) index
+    const int rowlen = Wout * 3;
+    if (xc >= rowlen) return;
+    const uint8_t* col = tmp + ((size_t)n * A.in_size + first) * rowlen + xc;
+    int acc = 1 << (kPilBits - 1);
+    for (int y = 0; y < count; ++y) acc += (int)col[(size_t)y * rowlen] * kk[y];
+    const int v = pil_clip8(acc);
+    if (out_u8) out_u8[((size_t)n * A.out_size + yy) * rowlen + xc] = (uint8_t)v;
+    if (out_f32) {
+        const int x = xc / 3, c = xc - 3 * x;
+        out_f32[(((size_t)n * 3 + c) * A.out_size + yy) * Wout + x] = (float)v / 255.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // the two resizes around the plane sweep (train.py:55 bilinear, train.py:60 bicubic; align_corners=False, size given,
 // so the scale is in/out in fp32 as ATen's area_pixel_compute_scale forms it).  One thread per output pixel.
 // ---------------------------------------------------------------------------------------------------
@@ -952,6 +1066,31 @@ int ds_ingest_u8(const uint8_t* frames, int N, int H, int W, float* out, void* s
     const int HW = H * W, groups = (HW + 3) / 4;
     hipLaunchKernelGGL(ingest_u8_kernel, dim3((groups + kThreads - 1) / kThreads, N), dim3(kThreads), 0, (hipStream_t)stream,
                        frames, HW, out);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+size_t ds_ingest_resize_workspace_bytes(int N, int Hin, int Win, int Hout, int Wout) {
+    if (N <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return 0;
+    return (size_t)N * Hin * Wout * 3;  // the horizontal pass's uint8 result
+}
+
+int ds_ingest_resize_u8(const uint8_t* frames, int N, int Hin, int Win, int Hout, int Wout, uint8_t* out_u8, float* out_f32,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!frames || (!out_u8 && !out_f32) || N <= 0 || N > 65535 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 ||
+        Hout > 65535 || (long long)Hin * Win > (1ll << 30) || (long long)Hout * Wout > (1ll << 30))
+        return DS_ERR_INVALID_ARG;
+    PilAxis ax, ay;
+    if (!pil_axis(ax, Win, Wout) || !pil_axis(ay, Hin, Hout)) return DS_ERR_UNSUPPORTED;  // more than 64 taps
+    if (!workspace || workspace_bytes < ds_ingest_resize_workspace_bytes(N, Hin, Win, Hout, Wout)) return DS_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t* tmp = (uint8_t*)workspace;
+    const int rows_per_block = 32;
+    hipLaunchKernelGGL(pil_resize_h_kernel, dim3((Wout + 63) / 64, (Hin + rows_per_block - 1) / rows_per_block, N),
+                       dim3(kThreads), 0, st, frames, ax, Hin, rows_per_block, tmp);
+    DS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pil_resize_v_kernel, dim3((Wout * 3 + kThreads - 1) / kThreads, Hout, N), dim3(kThreads), 0, st,
+                       (const uint8_t*)tmp, ay, Wout, out_u8, out_f32);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

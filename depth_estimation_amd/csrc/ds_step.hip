@@ -69,6 +69,12 @@ int ds_loss_step_bwd(const float* K, const float* Kinv, const float* pose, const
                        workspace_bytes, stream);
 }
 
+int ds_warp_identity_fwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                         const float* target, int B, int S, int H, int W, float* warped, float* idt_loss, void* stream) {
+    if (B <= 0 || S <= 0 || (long long)B * S > 65535) return DS_ERR_INVALID_ARG;
+    return ds::warp_and_identity(K, Kinv, pose, depth, src, target, B, S, H, W, warped, idt_loss, (hipStream_t)stream);
+}
+
 size_t ds_loss_step_fwdbwd_workspace_bytes(int B, int S, int H, int W) {
     if (B <= 0 || S <= 0 || H < 2 || W < 2) return 0;
     // both sets of partial sums stay live until the single finalize launch at the end

@@ -139,6 +139,12 @@ int ds_fused_loss_fwd(const float* warped, const float* src, const float* target
 int ds_fused_loss_bwd(const float* warped, const float* target, const float* idt_loss, const uint8_t* aux,
                       const float* g_sums, int B, int S, int H, int W, float* g_warped, void* stream);
 
+/* ds_warp_fwd (C = 3, source size = grid size) and the identity loss map of train.py:85 -- idt_loss (B,H,W) =
+ * metrics.reprojection_loss(src_imgs, target_imgs) per target, i.e. ds_reprojection_loss_fwd(src, target) -- in ONE
+ * launch: the identity term depends on neither depth nor pose, so its workgroups share the launch with the warp's. */
+int ds_warp_identity_fwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                         const float* target, int B, int S, int H, int W, float* warped, float* idt_loss, void* stream);
+
 /* Forward and backward of the warped groups in ONE kernel, given the identity map idt_loss (B,H,W) =
  * ds_reprojection_loss_fwd(src, target): out_loss, aux, sums as ds_fused_loss_fwd, g_warped as ds_fused_loss_bwd (g_sums
  * (B) or NULL = ones), bit for bit, without the backward's recomputation of the forward's window sums.  S <= 2
@@ -213,9 +219,19 @@ int ds_depth_metrics_noalloc(const float* pred, const float* gt, int B, int H, i
                              void* stream);
 
 /* Input pipeline to the device: torchvision.transforms.functional.to_tensor on the resized frame (dataset.py:51,110):
- * frames (N,H,W,3) uint8 interleaved -> out (N,3,H,W) fp32 = value / 255.  The PIL resize itself stays on the host.
+ * frames (N,H,W,3) uint8 interleaved -> out (N,3,H,W) fp32 = value / 255 (for frames resized on the host; see
+ * ds_ingest_resize_u8 for the resize itself).
  * frames 4-byte aligned, out 16-byte aligned. */
 int ds_ingest_u8(const uint8_t* frames, int N, int H, int W, float* out, void* stream);
+
+/* The resize of the loaders on the device (dataset.py:51,110: tf.resize(img, (192, 640)) on a PIL image = PIL's
+ * antialiased BILINEAR resize; Pillow's fixed-point arithmetic, bit-exact): raw frames (N,Hin,Win,3) uint8 interleaved ->
+ * out_u8 (N,Hout,Wout,3) uint8 (what PIL returns) and / or out_f32 (N,3,Hout,Wout) fp32 = value / 255 (to_tensor of it);
+ * either may be NULL.  workspace from ds_ingest_resize_workspace_bytes.  Down-scaling by more than ~31x per axis:
+ * DS_ERR_UNSUPPORTED. */
+size_t ds_ingest_resize_workspace_bytes(int N, int Hin, int Win, int Hout, int Wout);
+int ds_ingest_resize_u8(const uint8_t* frames, int N, int Hin, int Win, int Hout, int Wout, uint8_t* out_u8, float* out_f32,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* Ground-truth depth to the device (dataset.py:116-120): the resized 16-bit PNG samples (N,H,W) uint16 ->
  * out (N,1,H,W) fp32 = value / 2**16.  depth 4-byte aligned, out 8-byte aligned.  The reference holds no depth PNG

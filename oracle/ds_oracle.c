@@ -734,3 +734,75 @@ DSO_API void dso_resize_bicubic(const float* in, int N, int Hin, int Win, int Ho
             }
         }
 }
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* f.4  the resize of the loaders (dataset.py:51,110): tf.resize(img, (192, 640)) on a PIL     */
+/* image = PIL's Image.resize(BILINEAR).  The arithmetic lives in Pillow (libImaging/Resample.c, */
+/* absent from /root/reference; Pillow 12.2.0 in this image): a separable triangle filter whose   */
+/* support grows with the down-scale factor (antialiasing), coefficients normalised in double,    */
+/* rounded to 22-bit fixed point, each pass accumulated in int32 from 1 << 21 and clipped to      */
+/* 0..255; the horizontal pass comes first and its result is rounded to uint8 before the vertical */
+/* one.  Integer work: pinned bit-exact against PIL itself (tests/test_oracle_golden.py) and      */
+/* against the frames the golden fixtures hold.                                                    */
+/* ------------------------------------------------------------------------------------------ */
+#define DSO_PIL_PRECISION_BITS (32 - 8 - 2)
+
+static double dso_pil_triangle(double x) {
+    if (x < 0.0) x = -x;
+    return x < 1.0 ? 1.0 - x : 0.0;
+}
+
+/* coefficients of output sample xx along an axis of in_size -> out_size: first tap *xmin, count returned (<= ksize) */
+static int dso_pil_coeffs(int in_size, int out_size, int xx, int* xmin_out, int* kk, int ksize) {
+    double scale = (double)in_size / out_size, filterscale = scale < 1.0 ? 1.0 : scale;
+    double support = 1.0 * filterscale, center = (xx + 0.5) * scale, ss = 1.0 / filterscale, ww = 0.0;
+    double w[64];
+    int xmin = (int)(center - support + 0.5), xmax = (int)(center + support + 0.5), x;
+    if (xmin < 0) xmin = 0;
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    if (xmax > ksize) xmax = ksize;
+    for (x = 0; x < xmax; ++x) {
+        w[x] = dso_pil_triangle((x + xmin - center + 0.5) * ss);
+        ww += w[x];
+    }
+    for (x = 0; x < xmax; ++x) {
+        double k = ww != 0.0 ? w[x] / ww : w[x];
+        kk[x] = k < 0 ? (int)(-0.5 + k * (1 << DSO_PIL_PRECISION_BITS)) : (int)(0.5 + k * (1 << DSO_PIL_PRECISION_BITS));
+    }
+    *xmin_out = xmin;
+    return xmax;
+}
+
+static unsigned char dso_pil_clip8(int v) {
+    v >>= DSO_PIL_PRECISION_BITS;   /* arithmetic shift, as Pillow's lookup table index */
+    return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+/* in (Hin,Win,C) uint8 interleaved -> out (Hout,Wout,C) uint8; tmp (Hin,Wout,C) uint8 scratch; returns 0, or -1 if the
+ * filter would need more than 64 taps (down-scaling by more than ~31x) */
+DSO_API int dso_pil_resize_bilinear_u8(const unsigned char* in, int Hin, int Win, int C, int Hout, int Wout,
+                                       unsigned char* tmp, unsigned char* out) {
+    double sx = (double)Win / Wout, sy = (double)Hin / Hout;
+    int kx = (int)ceil(sx < 1.0 ? 1.0 : sx) * 2 + 1, ky = (int)ceil(sy < 1.0 ? 1.0 : sy) * 2 + 1;
+    if (kx > 64 || ky > 64) return -1;
+    for (int xx = 0; xx < Wout; ++xx) {
+        int kk[64], xmin, n = dso_pil_coeffs(Win, Wout, xx, &xmin, kk, kx);
+        for (int y = 0; y < Hin; ++y)
+            for (int c = 0; c < C; ++c) {
+                int acc = 1 << (DSO_PIL_PRECISION_BITS - 1);
+                for (int x = 0; x < n; ++x) acc += (int)in[((size_t)y * Win + xmin + x) * C + c] * kk[x];
+                tmp[((size_t)y * Wout + xx) * C + c] = dso_pil_clip8(acc);
+            }
+    }
+    for (int yy = 0; yy < Hout; ++yy) {
+        int kk[64], ymin, n = dso_pil_coeffs(Hin, Hout, yy, &ymin, kk, ky);
+        for (int x = 0; x < Wout * C; ++x) {
+            int acc = 1 << (DSO_PIL_PRECISION_BITS - 1);
+            for (int y = 0; y < n; ++y) acc += (int)tmp[(size_t)(ymin + y) * Wout * C + x] * kk[y];
+            out[(size_t)yy * Wout * C + x] = dso_pil_clip8(acc);
+        }
+    }
+    return 0;
+}

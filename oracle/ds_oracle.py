@@ -242,3 +242,18 @@ def resize_bilinear(x, size) -> np.ndarray:
 def resize_bicubic(x, size) -> np.ndarray:
     """functional.interpolate(x, size=size, mode="bicubic") of train.py:60; x (...,Hin,Win)."""
     return _resize(lib().dso_resize_bicubic, x, size)
+
+
+def pil_resize_bilinear_u8(frame, size) -> np.ndarray:
+    """f.4: PIL Image.resize(size, BILINEAR) of a (H,W,C) uint8 frame (what dataset.py:51,110 does through tf.resize);
+    size = (Hout, Wout) -> (Hout,Wout,C) uint8."""
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    H, W, Cc = frame.shape
+    ho, wo = int(size[0]), int(size[1])
+    tmp = np.empty((H, wo, Cc), np.uint8)
+    out = np.empty((ho, wo, Cc), np.uint8)
+    rc = lib().dso_pil_resize_bilinear_u8(frame.ctypes.data_as(_u8p), H, W, Cc, ho, wo, tmp.ctypes.data_as(_u8p),
+                                          out.ctypes.data_as(_u8p))
+    if rc != 0:
+        raise ValueError("scale factor beyond the 64-tap limit")
+    return out

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""profiles/pmc.json from the per-kernel PMC summaries of scripts/profile_round.sh:
+    python scripts/pmc_to_json.py <tag>      reads gpurun_out/pmc_<tag>_{FETCH_SIZE,WRITE_SIZE,SQ1}_<workload>.txt
+hbm_bytes = (FETCH_SIZE x 2 + WRITE_SIZE) KiB -> bytes per launch (x2: gfx950 counts the 128-B requests of coalesced
+streaming reads at 64 B, MI355X_MICROARCH.md HBM; uncalibrated for gather kernels); valu_wave_insts = SQ_INSTS_VALU."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+# bench.py's call names -> the kernels a call launches (finalize kernels: a single wave, left out)
+KERNELS = {"warp_identity": "warp_idt_kernel<2>", "loss_fb": "photo_fb_kernel<2>", "warp_bwd": "warp_bwd_kernel<3, false>",
+           "warp_fwd": "warp_fwd_kernel<3>", "loss_fwd": "photo_fwd_kernel<2, true>", "loss_bwd": "photo_bwd_kernel<2, true>",
+           "metrics": "metrics_kernel"}
+
+
+def read(path):
+    out, cur = {}, None
+    if not os.path.exists(path):
+        return out
+    for line in open(path):
+        m = re.match(r"^(\S.*?)\s+dispatches=(\d+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+        elif cur is not None and line.strip():
+            k, v = line.split()
+            cur[k] = float(v)
+    return out
+
+
+res = {"_comment": __doc__.strip().split("\n", 2)[2].strip() + f"  Source: gpurun_out/pmc_{tag}_* (copies under profiles/)."}
+for wl in ("b12_s2_192x640_fwdbwd", "b64_s2_320x1024_fwdbwd"):
+    f, w, q = [read(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{c}_{wl}.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ1")]
+    d = {}
+    for name, kern in KERNELS.items():
+        e = {}
+        if kern in f and kern in w:
+            e["hbm_bytes"] = int((2 * f[kern]["FETCH_SIZE"] + w[kern]["WRITE_SIZE"]) * 1024)
+        if kern in q and "SQ_INSTS_VALU" in q[kern]:
+            e["valu_wave_insts"] = int(q[kern]["SQ_INSTS_VALU"])
+        if e:
+            d[name] = e
+    if d:
+        res[wl] = d
+json.dump(res, open(os.path.join(ROOT, "profiles", "pmc.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))

@@ -592,6 +592,34 @@ def test_ingest_u8_matches_to_tensor(de):
         de.ingest.to_tensor(odd.to(DEV).float())      # wrong dtype
 
 
+def test_ingest_resize_matches_pil(de, oracle):
+    """SURVEY 8f.4 with the resize on the device: tf.to_tensor(tf.resize(img, (192, 640))) (dataset.py:51,110) from the RAW
+    uint8 frame == the frames / float tensors the reference-generated fixtures hold, bit-exact (Pillow's fixed-point
+    arithmetic is integer work); ragged sizes, up- and down-scaling, batches, against the oracle (itself pinned to PIL)."""
+    raw = np.load(os.path.join(os.path.dirname(__file__), "golden", "raw_frame_376x1241_u8.npz"))["frame"]
+    for name, size in (("real_192x640", (192, 640)), ("real_48x160", (48, 160))):
+        want_u8 = np.load(os.path.join(os.path.dirname(__file__), "golden", name + "_frames_u8.npz"))["frames"][0]
+        d = load_golden(name)
+        got_u8 = de.ingest.resize_u8(torch.from_numpy(raw).to(DEV), size)
+        assert got_u8.dtype == torch.uint8 and np.array_equal(N(got_u8), want_u8)
+        got_f = de.ingest.resize_to_tensor(torch.from_numpy(raw).to(DEV), size)
+        assert np.array_equal(N(got_f), d["src"][0])              # frame 0 is the first source of the fixture
+        assert np.array_equal(N(de.ingest.to_tensor(got_u8)), d["src"][0])
+    rng = np.random.default_rng(1)
+    for H, W, ho, wo in ((37, 53, 19, 20), (19, 20, 37, 53), (64, 64, 64, 64), (90, 7, 3, 50), (5, 5, 11, 2), (1, 1, 4, 4),
+                         (400, 300, 13, 17), (33, 1000, 33, 40), (376, 1241, 96, 320)):
+        a = rng.integers(0, 256, (3, H, W, 3), dtype=np.uint8)
+        want = np.stack([oracle.pil_resize_bilinear_u8(f, (ho, wo)) for f in a])
+        got = de.ingest.resize_u8(torch.from_numpy(a).to(DEV), (ho, wo))
+        assert np.array_equal(N(got), want), (H, W, ho, wo)
+        gf = de.ingest.resize_to_tensor(torch.from_numpy(a).to(DEV), (ho, wo))
+        assert np.array_equal(N(gf), (want.astype(np.float32) / np.float32(255)).transpose(0, 3, 1, 2))
+    with pytest.raises(RuntimeError):
+        de.ingest.resize_u8(torch.zeros(100, 7, 3, dtype=torch.uint8, device=DEV), (3, 50))   # 33x down: unsupported
+    with pytest.raises(RuntimeError):
+        de.ingest.resize_u8(torch.zeros(8, 8, 3, dtype=torch.uint8), (4, 4))                  # CPU tensor
+
+
 def test_ingest_depth_u16(de):
     """dataset.py:116-120: 16-bit ground-truth samples / 2**16.  The reference holds no depth PNG and torchvision is not
     installed: parity unpinned, checked bit-exact against the direct statement on every 16-bit value and a ragged size."""

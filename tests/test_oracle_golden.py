@@ -3,6 +3,8 @@
 CPU-only.  Bit-exact (CRC32 of the raw fp32 bytes) for every forward stage that has no
 transcendental in it; 1e-4 relative-to-max for gradients and scalars (BASELINE.json tolerance).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -171,3 +173,27 @@ def test_depth_metrics(oracle):
     assert got.dtype == np.int64 and np.array_equal(got, want)
     for i, k in enumerate(("delta1", "delta2", "delta3")):
         assert abs(m[k] - (want[:, i] / p32.shape[1]).mean()) < 1e-12
+
+
+RESIZE_U8_SIZES = [(37, 53, 19, 20), (19, 20, 37, 53), (64, 64, 64, 64), (90, 7, 3, 50), (5, 5, 11, 2), (192, 640, 96, 320),
+                   (1, 1, 4, 4), (400, 300, 13, 17), (2, 3, 2, 3), (33, 1000, 33, 40)]
+
+
+def test_pil_resize_restatement(oracle):
+    """f.4 (dataset.py:51,110): the oracle's restatement of Pillow's antialiased BILINEAR resize, bit-exact (integer
+    arithmetic) against (a) the resized frames the reference-generated fixtures hold, from the raw 1241x376 frame they were
+    made of, and (b) PIL itself (a third-party package of this image, not the reference) on ragged sizes, up- and
+    down-scaling."""
+    raw = np.load(os.path.join(os.path.dirname(__file__), "golden", "raw_frame_376x1241_u8.npz"))["frame"]
+    assert raw.shape == (376, 1241, 3) and raw.dtype == np.uint8
+    for name, size in (("real_192x640", (192, 640)), ("real_48x160", (48, 160))):
+        want = np.load(os.path.join(os.path.dirname(__file__), "golden", name + "_frames_u8.npz"))["frames"][0]
+        assert np.array_equal(oracle.pil_resize_bilinear_u8(raw, size), want), name
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(0)
+    for H, W, ho, wo in RESIZE_U8_SIZES:
+        a = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        want = np.asarray(Image.fromarray(a).resize((wo, ho), Image.BILINEAR))
+        assert np.array_equal(oracle.pil_resize_bilinear_u8(a, (ho, wo)), want), (H, W, ho, wo)
+    with pytest.raises(ValueError):
+        oracle.pil_resize_bilinear_u8(np.zeros((100, 7, 3), np.uint8), (3, 50))   # 33x down: beyond the 64-tap limit

@@ -319,10 +319,26 @@ def case_ssim_grad(name):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
 
 
+def case_raw_frame(name):
+    """One raw 1241x376 frame of test_data_copy as uint8 (data, not source): the input of the loaders' resize
+    (dataset.py:44-51).  Its PIL-resized forms are frame 0 of real_192x640_frames_u8 / real_48x160_frames_u8, which this
+    checks before writing."""
+    im = Image.open(f"{REF}/test_data_copy/{0:010d}.png").convert("RGB")
+    raw = np.asarray(im, dtype=np.uint8)
+    for fx, (w, h) in (("real_192x640", (640, 192)), ("real_48x160", (160, 48))):
+        have = np.load(os.path.join(OUT, fx + "_frames_u8.npz"))["frames"][0]
+        assert np.array_equal(np.asarray(im.resize((w, h), Image.BILINEAR), dtype=np.uint8), have), fx
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), frame=raw)
+    print(name, raw.shape)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if sys.argv[1:] == ["resize"]:                                # added later; leaves the other fixtures untouched
         case_resize("resize_vectors")
+        return
+    if sys.argv[1:] == ["raw_frame"]:                             # round 2; reads two fixtures, rewrites none
+        case_raw_frame("raw_frame_376x1241_u8")
         return
     if sys.argv[1:] == ["ssim_grad"]:                             # round 2; reads the loss fixtures, rewrites none
         case_ssim_grad("ssim_grad")
