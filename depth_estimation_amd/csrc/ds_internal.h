@@ -66,6 +66,15 @@ DS_HIDDEN size_t fused_loss_fb_workspace_bytes(int B, int H, int W);
 DS_HIDDEN int fused_loss_fb_partials(const float* warped, const float* target, const float* idt_loss, const float* g_sums,
                                      int B, int S, int H, int W, float* out_loss, uint8_t* aux, float* g_warped,
                                      void* workspace, size_t workspace_bytes, int* waves_per_image, hipStream_t stream);
+// the same kernel with the warp's autograd in its fourth wave: d loss / d warped goes from the channel waves to it through
+// LDS (g_warped may be NULL: then it never reaches memory), g_depth and per-workgroup pose partials come out;
+// *pose_partials (B*S, *waves_per_image, 12) lies inside `workspace`
+DS_HIDDEN size_t fused_loss_fbw_workspace_bytes(int B, int S, int H, int W);
+DS_HIDDEN int fused_loss_fbw_partials(const float* K, const float* Kinv, const float* pose, const float* depth,
+                                      const float* src, const float* warped, const float* target, const float* idt_loss,
+                                      const float* g_sums, int B, int S, int H, int W, float* out_loss, uint8_t* aux,
+                                      float* g_warped, float* g_depth, void* workspace, size_t workspace_bytes,
+                                      int* waves_per_image, float** pose_partials, hipStream_t stream);
 // main kernel of ds_warp_bwd; *nblk = pose-gradient partials per image in `workspace`
 DS_HIDDEN int warp_bwd_partials(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
                                 const float* g_warped, int N, int C, int Hs, int Ws, int H, int W, float* g_depth,

@@ -804,10 +804,17 @@ struct PhotoFbParams {
     float* out;             // (B,H,W)
     uint8_t* aux;           // (B,H,W)
     float* wave_partials;   // (nblocks, 2)
-    float* g_preds;         // (B, S, 3, H, W)
+    float* g_preds;         // (B, S, 3, H, W); may be NULL with WARP (d loss / d warped then never reaches memory)
+    // WARP: the fourth wave also runs the warp's autograd on the rows the channel waves finish (ds_warp_bwd's arithmetic)
+    const float* K; const float* Kinv; const float* pose;   // (4,4), (4,4), (B*S,3,4)
+    const float* depth;     // (B, S, H, W)
+    const float* src;       // (B, S, 3, H, W)
+    float* g_depth;         // (B, S, H, W)
+    float* pose_partials;   // (B*S, nbx*nby, 12)
+    ds::WarpGeom G;
 };
 
-template <int S>
+template <int S, bool WARP>
 __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kernel(PhotoFbParams P) {
     constexpr int NP = 1 + S;  // raw planes of a channel: target, then the S warped groups
     constexpr int NK = 3 * S;  // masked tap coefficients: (A, B, C) per source
@@ -816,6 +823,7 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
     __shared__ float lds_k[3][NK][kLdsRow];
     __shared__ float lds_e[2][kK][3][S][64];
     __shared__ float lds_p[3][kK][NP + 1][64];  // per channel wave: centre values and identity loss of the pending rows
+    __shared__ float lds_g[WARP ? 2 : 1][kK][3][WARP ? S : 1][WARP ? 64 : 1];  // WARP: rows of d loss / d warped for the 4th wave
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int role = (wave + (int)(blockIdx.x >> 3)) & 3;  // 0..2 = channel, 3 = output wave
     const int lane = threadIdx.x & 63;
@@ -830,35 +838,118 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
     const bool lane_out = lane >= 1 && lane <= 62 && col < W;
 
     if (role == 3) {
-        // ---------------------------------------------------------------------------------- output wave
+        // ---------------------------------------------------------------------------------- output (and warp) wave
         const rsrc_t ip = make_rsrc(P.idt + (size_t)b * HW);
         const unsigned cl = (unsigned)reflect_idx(col, W) * 4u;
         float sum_ratio = 0.f, sum_out = 0.f;
-        for (int sl = 0; sl < nslab; ++sl) {
-            // identity values of this slab's rows, requested before the wait
-            float iv[kK];
+        // WARP: the autograd of the warp for the rows of d loss / d warped the channel waves finished one barrier ago --
+        // per pixel exactly ds_warp_bwd's arithmetic (project_pixel_lean, make_tap, corner pairs, grid-sample border
+        // rule, chain back to depth and pose); the rows come through lds_g instead of memory.
+        const int xc = min(max(col, 0), W - 1);
+        const unsigned xb = (unsigned)xc * 4u;
+        const unsigned HsWs = (unsigned)HW;
+        Cam cam[WARP ? S : 1];
+        float gM[WARP ? S : 1][12];
+        if (WARP) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                load_cam(cam[s], P.K, P.Kinv, P.pose + 12 * (b * S + s));
+#pragma unroll
+                for (int i = 0; i < 12; ++i) gM[s][i] = 0.f;
+            }
+        }
+        const float sxg = WARP ? (P.G.w1 * 0.5f) * (2.0f * P.G.rw1) : 0.f, syg = WARP ? (P.G.h1 * 0.5f) * (2.0f * P.G.rh1) : 0.f;
+        const int niter = WARP ? nslab + 1 : nslab;
+        for (int sl = 0; sl < niter; ++sl) {
+            // identity values of this slab's rows and depths of the rows to differentiate, requested before the wait
+            float iv[kK], dep[kK][S];
 #pragma unroll
             for (int k = 0; k < kK; ++k) iv[k] = buf_load_f32(ip, cl, (unsigned)(reflect_idx(y0 - 1 + sl * kK + k, H) * W));
-            __syncthreads();  // the channel waves have filled slab sl & 1
+            if (WARP) {
+#pragma unroll
+                for (int k = 0; k < kK; ++k) {
+                    const int t = min(max(y0 - 2 + (sl - 1) * kK + k, 0), H - 1);
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+                        dep[k][s] = buf_load_f32(make_rsrc(P.depth + (size_t)(b * S + s) * HW), xb, (unsigned)(t * W));
+                }
+            }
+            __syncthreads();  // the channel waves have filled slab sl & 1 (and the rows of d loss / d warped before it)
             const int buf = sl & 1;
+            if (sl < nslab) {
 #pragma unroll
-            for (int k = 0; k < kK; ++k) {
-                const int y = y0 - 1 + sl * kK + k;
-                float E[S];
+                for (int k = 0; k < kK; ++k) {
+                    const int y = y0 - 1 + sl * kK + k;
+                    float E[S];
 #pragma unroll
-                for (int g = 0; g < S; ++g)
-                    E[g] = div3((lds_e[buf][k][0][g][lane] + lds_e[buf][k][1][g][lane]) + lds_e[buf][k][2][g][lane]);
-                float best = E[0];
-                int bi = 0;
+                    for (int g = 0; g < S; ++g)
+                        E[g] = div3((lds_e[buf][k][0][g][lane] + lds_e[buf][k][1][g][lane]) + lds_e[buf][k][2][g][lane]);
+                    float best = E[0];
+                    int bi = 0;
 #pragma unroll
-                for (int g = 1; g < S; ++g)
-                    if (E[g] < best) { best = E[g]; bi = g; }
-                if (lane_out && y >= y0 && y < yend) {
-                    const size_t o = (size_t)b * HW + (size_t)y * W + col;
-                    P.out[o] = best;
-                    P.aux[o] = (uint8_t)bi;
-                    sum_ratio += best / expf(iv[k] + 1e-6f);  // train.py:88
-                    sum_out += best;                          // train.py:92
+                    for (int g = 1; g < S; ++g)
+                        if (E[g] < best) { best = E[g]; bi = g; }
+                    if (lane_out && y >= y0 && y < yend) {
+                        const size_t o = (size_t)b * HW + (size_t)y * W + col;
+                        P.out[o] = best;
+                        P.aux[o] = (uint8_t)bi;
+                        sum_ratio += best / expf(iv[k] + 1e-6f);  // train.py:88
+                        sum_out += best;                          // train.py:92
+                    }
+                }
+            }
+            if (WARP && sl >= 1) {
+                const int gbuf = (sl - 1) & 1;
+#pragma unroll
+                for (int k = 0; k < kK; ++k) {
+                    const int t = y0 - 2 + (sl - 1) * kK + k;   // output row of window row y0-1 + (sl-1)*kK + k
+                    if (t < y0 || t >= yend) continue;          // uniform
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {   // one source at a time: two in flight need 30 more registers than there are
+                        Proj pr;
+                        float rz;
+                        Tap tp;
+                        float2_t top[3], bot[3];
+                        project_pixel_lean(cam[s], (float)xc, (float)t, dep[k][s], pr, rz);
+                        make_tap(pr.u, pr.v, P.G, tp);
+                        const rsrc_t sp = make_rsrc(P.src + (size_t)(b * S + s) * 3 * HW);
+#pragma unroll
+                        for (int ch3 = 0; ch3 < 3; ++ch3) {
+                            top[ch3] = buf_load_f32x2(sp, tp.o_top, ch3 * HsWs * 4u);
+                            bot[ch3] = buf_load_f32x2(sp, tp.o_bot, ch3 * HsWs * 4u);
+                        }
+                        float gix = 0.f, giy = 0.f;
+#pragma unroll
+                        for (int ch3 = 0; ch3 < 3; ++ch3) {
+                            const float gc = lane_out ? lds_g[gbuf][k][ch3][s][lane] : 0.0f;
+                            const float2_t a = top[ch3], bb = bot[ch3];
+                            const float nw = tp.shift ? a.y : a.x, ne = a.y, sw = tp.shift ? bb.y : bb.x, se = bb.y;
+                            gix = fmaf(gc, fmaf(ne - nw, tp.sy, (se - sw) * tp.ny), gix);
+                            giy = fmaf(gc, fmaf(sw - nw, tp.ex, (se - ne) * tp.wx), giy);
+                        }
+                        // torch grid_sampler_2d backward: zero on or outside the border of the un-clipped coordinate
+                        gix = (tp.ixu > 0.0f && tp.ixu < P.G.w1) ? gix * sxg : 0.0f;
+                        giy = (tp.iyu > 0.0f && tp.iyu < P.G.h1) ? giy * syg : 0.0f;
+                        if (!lane_out) gix = giy = 0.0f;   // halo lanes and lanes beyond the image
+                        const float gq0 = gix * rz, gq1 = giy * rz;
+                        const float gq2 = (fabsf(pr.q[2]) < 1e-6f) ? 0.0f : -(fmaf(pr.u, gix, pr.v * giy)) * rz;
+                        float gT[3], gP[3];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            gT[q] = fmaf(cam[s].K[6 + q], gq2, fmaf(cam[s].K[3 + q], gq1, cam[s].K[q] * gq0));
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            gP[q] = fmaf(cam[s].M[8 + q], gT[2], fmaf(cam[s].M[4 + q], gT[1], cam[s].M[q] * gT[0]));
+                        const float gd = fmaf(pr.c[2], gP[2], fmaf(pr.c[1], gP[1], pr.c[0] * gP[0]));
+#pragma unroll
+                        for (int j2 = 0; j2 < 3; ++j2) {
+                            gM[s][4 * j2 + 0] = fmaf(gT[j2], pr.P[0], gM[s][4 * j2 + 0]);
+                            gM[s][4 * j2 + 1] = fmaf(gT[j2], pr.P[1], gM[s][4 * j2 + 1]);
+                            gM[s][4 * j2 + 2] = fmaf(gT[j2], pr.P[2], gM[s][4 * j2 + 2]);
+                            gM[s][4 * j2 + 3] += gT[j2];
+                        }
+                        if (lane_out) P.g_depth[(size_t)(b * S + s) * HW + (size_t)t * W + col] = gd;
+                    }
                 }
             }
         }
@@ -867,6 +958,17 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
         if (lane == 0) {
             P.wave_partials[2 * wg + 0] = sum_ratio;
             P.wave_partials[2 * wg + 1] = sum_out;
+        }
+        if (WARP) {
+            const int per_image = P.nbx * P.nby, slot = by * P.nbx + bx;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    const float v = wave_sum(gM[s][i]);
+                    if (lane == 0) P.pose_partials[((size_t)(b * S + s) * per_image + slot) * 12 + i] = v;
+                }
+            }
         }
         return;
     }
@@ -883,7 +985,8 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
     const rsrc_t tp = make_rsrc(P.target + (size_t)b * 3 * HW);
     const rsrc_t pp = make_rsrc(P.preds + (size_t)b * (S * 3 * HW));
     const rsrc_t ip = make_rsrc(P.idt + (size_t)b * HW);
-    const rsrc_t gp = make_rsrc(P.g_preds + (size_t)b * (S * 3 * HW));
+    const bool store_g = P.g_preds != nullptr;   // uniform
+    const rsrc_t gp = make_rsrc(store_g ? P.g_preds + (size_t)b * (S * 3 * HW) : P.out);
     const float gscale = P.g_sums ? P.g_sums[b] * P.inv_hw : P.inv_hw;
     float (*lr)[kLdsRow] = lds_raw[c];
     float (*lk)[kLdsRow] = lds_k[c];
@@ -1079,7 +1182,9 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
                     const float diff = Y - X;
                     const float sgn = diff > 0.f ? -1.0f : (diff < 0.f ? 1.0f : 0.0f);
                     if (pam == s) gg = fmaf(0.15f * ge, sgn, gg);
-                    if (lane_out) buf_store_f32(gg, gp, (unsigned)col * 4u, ((s * 3 + c) * uHW + (unsigned)(t * W)) * 4u);
+                    if (WARP) lds_g[buf][k][c][s][lane] = gg;
+                    if (store_g && lane_out)
+                        buf_store_f32(gg, gp, (unsigned)col * 4u, ((s * 3 + c) * uHW + (unsigned)(t * W)) * 4u);
                 }
             }
 #pragma unroll
@@ -1094,6 +1199,7 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
         }
     }
 #undef DS_FB_RAW_ROW
+    if (WARP) __syncthreads();  // the fourth wave's last iteration: it takes the rows of the last slab after this barrier
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1523,10 +1629,45 @@ int ds::fused_loss_fb_partials(const float* warped, const float* target, const f
     P.inv_hw = (float)(1.0 / ((double)H * W));
     P.out = out_loss; P.aux = aux; P.wave_partials = (float*)workspace; P.g_preds = g_warped;
     const dim3 grid(g.nblocks), block(64 * kFwdWaves);
-    if (S == 1) hipLaunchKernelGGL((photo_fb_kernel<1>), grid, block, 0, stream, P);
-    else hipLaunchKernelGGL((photo_fb_kernel<2>), grid, block, 0, stream, P);
+    if (S == 1) hipLaunchKernelGGL((photo_fb_kernel<1, false>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((photo_fb_kernel<2, false>), grid, block, 0, stream, P);
     DS_CHECK_LAUNCH();
     *waves_per_image = g.nbx * g.nby;
+    return DS_OK;
+}
+
+size_t ds::fused_loss_fbw_workspace_bytes(int B, int S, int H, int W) {
+    if (B <= 0 || S <= 0 || H < 2 || W < 2) return 0;
+    const Geom g = make_fb_geom(B, H, W);
+    // per-workgroup loss partials, then per-workgroup pose partials of every (target, source)
+    return (size_t)g.nwaves * 2 * sizeof(float) + (size_t)g.nwaves * S * 12 * sizeof(float);
+}
+
+int ds::fused_loss_fbw_partials(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                                const float* warped, const float* target, const float* idt_loss, const float* g_sums, int B,
+                                int S, int H, int W, float* out_loss, uint8_t* aux, float* g_warped, float* g_depth,
+                                void* workspace, size_t workspace_bytes, int* waves_per_image, float** pose_partials,
+                                hipStream_t stream) {
+    if (!K || !Kinv || !pose || !depth || !src || !warped || !target || !idt_loss || !out_loss || !aux || !g_depth ||
+        bad_dims(B, S, H, W) || (long long)B * S > 65535)
+        return DS_ERR_INVALID_ARG;
+    if (!fused_loss_fb_supported(S)) return DS_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < fused_loss_fbw_workspace_bytes(B, S, H, W)) return DS_ERR_WORKSPACE;
+    const Geom g = make_fb_geom(B, H, W);
+    PhotoFbParams P{};
+    P.preds = warped; P.target = target; P.idt = idt_loss; P.g_sums = g_sums;
+    P.B = B; P.H = H; P.W = W; P.nbx = g.nbx; P.nby = g.nby; P.RB = g.RB;
+    P.inv_hw = (float)(1.0 / ((double)H * W));
+    P.out = out_loss; P.aux = aux; P.wave_partials = (float*)workspace; P.g_preds = g_warped;
+    P.K = K; P.Kinv = Kinv; P.pose = pose; P.depth = depth; P.src = src; P.g_depth = g_depth;
+    P.pose_partials = (float*)workspace + (size_t)g.nwaves * 2;
+    P.G = warp_geom(H, W, H, W);
+    const dim3 grid(g.nblocks), block(64 * kFwdWaves);
+    if (S == 1) hipLaunchKernelGGL((photo_fb_kernel<1, true>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((photo_fb_kernel<2, true>), grid, block, 0, stream, P);
+    DS_CHECK_LAUNCH();
+    *waves_per_image = g.nbx * g.nby;
+    *pose_partials = P.pose_partials;
     return DS_OK;
 }
 

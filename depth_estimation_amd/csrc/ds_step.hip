@@ -78,7 +78,9 @@ int ds_warp_identity_fwd(const float* K, const float* Kinv, const float* pose, c
 size_t ds_loss_step_fwdbwd_workspace_bytes(int B, int S, int H, int W) {
     if (B <= 0 || S <= 0 || H < 2 || W < 2) return 0;
     // both sets of partial sums stay live until the single finalize launch at the end
-    return loss_partials_bytes(B, H, W) + ds_warp_bwd_workspace_bytes(B * S, H, W);
+    const size_t a = loss_partials_bytes(B, H, W) + ds_warp_bwd_workspace_bytes(B * S, H, W);
+    const size_t b = ds::fused_loss_fb_supported(S) ? ds::fused_loss_fbw_workspace_bytes(B, S, H, W) : 0;
+    return a > b ? a : b;
 }
 
 int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
@@ -103,9 +105,16 @@ int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, co
         // sums are the forward's
         rc = ds::warp_and_identity(K, Kinv, pose, depth, src, target, B, S, H, W, warped, idt_loss, st);
         if (rc != DS_OK) return rc;
-        rc = ds::fused_loss_fb_partials(warped, target, idt_loss, g_sums, B, S, H, W, out_loss, aux, g_warped, ws_loss, n_loss,
-                                        &wpi, st);
+        // ... and that kernel's fourth wave runs the warp's autograd on the rows of d loss / d warped as they are finished:
+        // they never reach memory (g_warped stays untouched), and the step is three dependent launches and a finalize
+        float* pose_partials = nullptr;
+        rc = ds::fused_loss_fbw_partials(K, Kinv, pose, depth, src, warped, target, idt_loss, g_sums, B, S, H, W, out_loss, aux,
+                                         nullptr, g_depth, workspace, workspace_bytes, &wpi, &pose_partials, st);
         if (rc != DS_OK) return rc;
+        hipLaunchKernelGGL(step_finalize_kernel, dim3(B + B * S), dim3(64), 0, st, (const float*)workspace, wpi,
+                           1.0 / ((double)H * W), sums, B, (const float*)pose_partials, wpi, g_pose);
+        DS_CHECK_LAUNCH();
+        return DS_OK;
     } else {
         rc = ds_warp_fwd(K, Kinv, pose, depth, src, B * S, 3, H, W, H, W, warped, stream);
         if (rc != DS_OK) return rc;

@@ -173,7 +173,8 @@ int ds_loss_step_bwd(const float* K, const float* Kinv, const float* pose, const
  * sums[b][0], so the gradients can be formed before the caller's backward runs: g_sums (B) = d(loss)/d(sums[b][0]), or
  * NULL for a unit upstream gradient -- what loss.backward() passes for the reference's summed loss (train.py:88,103); a
  * caller with another upstream factor scales g_depth and g_pose by it.  Outputs as in the four calls it replaces;
- * g_warped (B,S,3,H,W) is scratch.  workspace 16-byte aligned, sized by ds_loss_step_fwdbwd_workspace_bytes. */
+ * g_warped (B,S,3,H,W) is scratch (for S <= 2 the gradient w.r.t. the warped images passes from the loss kernel's
+ * waves to the warp's autograd inside one kernel and the buffer is left untouched).  workspace 16-byte aligned, sized by ds_loss_step_fwdbwd_workspace_bytes. */
 size_t ds_loss_step_fwdbwd_workspace_bytes(int B, int S, int H, int W);
 int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
                         const float* target, const float* g_sums, int B, int S, int H, int W, float* warped,
