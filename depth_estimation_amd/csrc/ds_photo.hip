@@ -905,7 +905,9 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
                     const int t = y0 - 2 + (sl - 1) * kK + k;   // output row of window row y0-1 + (sl-1)*kK + k
                     if (t < y0 || t >= yend) continue;          // uniform
 #pragma unroll
-                    for (int s = 0; s < S; ++s) {   // one source at a time: two in flight need 30 more registers than there are
+                    for (int s = 0; s < S; ++s) {   // one source at a time: with two in flight the kernel spills (+13 % / +22 % run
+                                                    // time), with three waves per SIMD to make room +22 % / +8 %
+                                                    // (profiles/r02_kb4_warp_wave_variants.txt)
                         Proj pr;
                         float rz;
                         Tap tp;
