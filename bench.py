@@ -88,9 +88,9 @@ class Scale:
         p = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
         lib, N = self.lib, self.N
         # The launches of a step, individually callable (per-kernel timing).  Without the image gradient and with S <= 2
-        # the step is what ds_loss_step_fwdbwd launches: warp + identity map in one launch, forward+backward of the warped
-        # groups in one kernel, warp backward; otherwise the four classic calls.
-        self.fused_path = (not image_grad) and S <= 2
+        # the step is what ds_loss_step_fwdbwd launches: warp + identity map in one launch, then forward+backward of the
+        # warped groups with the warp's autograd in one kernel; otherwise the four classic calls.
+        self.fused_path = S <= 2
         if metrics:
             # test.py:73-81 on the first source's depth map; ground truth U(1,80) with 30 % invalid (zero) pixels
             self.gt = (1 + 79 * torch.rand(B, 1, H, W, generator=g)).to(dev)
@@ -99,27 +99,45 @@ class Scale:
             self.met = torch.empty(8, **f)
             self.ws_met_n = self.lib.ds_metrics_workspace_bytes(B, H, W)
             self.ws_met = torch.empty(self.ws_met_n, dtype=torch.uint8, device=dev)
-        self.ws_fb_n = self.lib.ds_fused_loss_fb_workspace_bytes(B, H, W)
+        self.ws_fb_n = self.lib.ds_fused_loss_fb_warp_bwd_workspace_bytes(B, S, H, W)
         self.ws_fb = torch.empty(max(self.ws_fb_n, 16), dtype=torch.uint8, device=dev)
         px, tp = self.N * H * W, B * H * W
         warp_bwd = lambda st: lib.ds_warp_bwd(p(self.K), p(self.Kinv), p(self.pose), p(self.depth), p(self.src),  # noqa: E731
                                               p(self.g_warped), N, 3, H, W, H, W, p(self.g_depth), p(self.g_pose),
                                               p(self.g_src), p(self.ws_warp), self.ws_warp_n, st)
         # algorithmic HBM bytes of each call: every input read once, every output written once
-        if self.fused_path:
+        warp_identity = lambda st: lib.ds_warp_identity_fwd(p(self.K), p(self.Kinv), p(self.pose), p(self.depth),  # noqa: E731
+                                                            p(self.src), p(self.tgt), B, S, H, W, p(self.warped), p(self.idt), st)
+        if self.fused_path and image_grad:
+            # with the image gradient d loss / d warped goes through memory to the scattering warp backward kernel
+            self.ws_fb2_n = self.lib.ds_fused_loss_fb_workspace_bytes(B, H, W)
+            self.ws_fb2 = torch.empty(max(self.ws_fb2_n, 16), dtype=torch.uint8, device=dev)
+            self.calls = {
+                "warp_identity": warp_identity,
+                "loss_fb": lambda st: lib.ds_fused_loss_fb(p(self.warped), p(self.tgt), p(self.idt), 0, B, S, H, W, p(self.out),
+                                                           p(self.aux), p(self.sums), p(self.g_warped), p(self.ws_fb2),
+                                                           self.ws_fb2_n, st),
+                "warp_bwd": warp_bwd,
+            }
+            self.alg_bytes = {
+                "warp_identity": px * (4 + 12 + 12) + tp * (12 + 4),
+                "loss_fb": px * (12 + 12) + tp * (12 + 4 + 4 + 1),     # warped + target + idt -> g_warped, out, aux
+                "warp_bwd": px * (4 + 12 + 12 + 4 + 12),               # depth + src + g_warped -> g_depth, g_src
+            }
+        elif self.fused_path:
             self.calls = {
                 "warp_identity": lambda st: lib.ds_warp_identity_fwd(p(self.K), p(self.Kinv), p(self.pose), p(self.depth),
                                                                      p(self.src), p(self.tgt), B, S, H, W, p(self.warped),
                                                                      p(self.idt), st),
-                "loss_fb": lambda st: lib.ds_fused_loss_fb(p(self.warped), p(self.tgt), p(self.idt), 0, B, S, H, W, p(self.out),
-                                                           p(self.aux), p(self.sums), p(self.g_warped), p(self.ws_fb),
-                                                           self.ws_fb_n, st),
-                "warp_bwd": warp_bwd,
+                "loss_fb_warp_bwd": lambda st: lib.ds_fused_loss_fb_warp_bwd(
+                    p(self.K), p(self.Kinv), p(self.pose), p(self.depth), p(self.src), p(self.warped), p(self.tgt), p(self.idt), 0,
+                    B, S, H, W, p(self.out), p(self.aux), p(self.sums), 0, p(self.g_depth), p(self.g_pose), p(self.ws_fb),
+                    self.ws_fb_n, st),
             }
             self.alg_bytes = {
                 "warp_identity": px * (4 + 12 + 12) + tp * (12 + 4),   # depth + src -> warped; + target -> idt
-                "loss_fb": px * (12 + 12) + tp * (12 + 4 + 4 + 1),     # warped + target + idt -> g_warped, out, aux
-                "warp_bwd": px * (4 + 12 + 12 + 4),                    # depth + src + g_warped -> g_depth
+                # warped + depth + src (gather) -> g_depth; + target + idt -> out, aux (d loss / d warped stays on chip)
+                "loss_fb_warp_bwd": px * (12 + 4 + 12 + 4) + tp * (12 + 4 + 4 + 1),
             }
         else:
             self.calls = {
@@ -139,14 +157,14 @@ class Scale:
                 "warp_bwd": px * (4 + 12 + 12 + 4 + (12 if image_grad else 0)),  # depth + src + g_warped -> g_depth [+ g_src]
             }
         self.names = tuple(self.calls) + (("metrics",) if metrics else ())
-        # the step as ONE call (forward + backward launches and a single merged finalize); the image-gradient scatter is
-        # only in the four-call form
+        # the step as ONE call (forward + backward launches and a single merged finalize; with the image gradient also the
+        # clearing of g_src)
         self.ws_step_n = self.lib.ds_loss_step_fwdbwd_workspace_bytes(B, S, H, W)
         self.ws_step = torch.empty(self.ws_step_n, dtype=torch.uint8, device=dev)
-        self.one_call = None if image_grad else (lambda st: lib.ds_loss_step_fwdbwd(
+        self.one_call = lambda st: lib.ds_loss_step_fwdbwd(
             p(self.K), p(self.Kinv), p(self.pose), p(self.depth), p(self.src), p(self.tgt), 0, B, S, H, W, p(self.warped),
             p(self.out), p(self.idt), p(self.aux), p(self.sums), p(self.g_warped), p(self.g_depth), p(self.g_pose),
-            p(self.ws_step), self.ws_step_n, st))
+            p(self.g_src), p(self.ws_step), self.ws_step_n, st)
         if metrics:
             self.calls["metrics"] = lambda st: lib.ds_depth_metrics(p(self.pred), p(self.gt), B, H, W, p(self.met), 0,
                                                                     p(self.ws_met), self.ws_met_n, st)
@@ -426,14 +444,8 @@ def main():
         side = [torch.cuda.Stream() for _ in parts]
 
         def pstep():
-            for sc in parts:
-                if sc.g_src is not None:
-                    sc.g_src.zero_()
-            for name in parts[0].names:
-                for j, sc in enumerate(parts):
-                    rc = sc.calls[name](side[j].cuda_stream)
-                    if rc != 0:
-                        sc.L.check(rc, name)
+            for j, sc in enumerate(parts):
+                sc.step(side[j].cuda_stream)
 
         n = max(10, args.steps // 2)
         for _ in range(min(args.warmup, 10)):
@@ -460,7 +472,7 @@ def main():
                        "height": wl["H"], "width": wl["W"], "scales": wl["scales"], "image_grad": bool(image_grad),
                        "metrics_reduce": bool(wl.get("metrics", False)),
                        "launch": "eager, whole batch on one stream, steps ordered (joined); " +
-                                 ("four C-ABI calls per level" if image_grad else "one C-ABI call per step (ds_loss_step_fwdbwd)"),
+                                 ("one C-ABI call per pyramid level (ds_loss_step_fwdbwd)" if wl["scales"] > 1 else "one C-ABI call per step (ds_loss_step_fwdbwd)"),
                        "parallelism": f"batch-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(hbm_frac, 4), "traffic": traffic,

@@ -51,11 +51,13 @@ _SIGNATURES = {
     "ds_warp_identity_fwd": (_i, [_fp] * 6 + [_i] * 4 + [_fp, _fp, _fp]),
     "ds_fused_loss_fb_workspace_bytes": (_sz, [_i, _i, _i]),
     "ds_fused_loss_fb": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "ds_fused_loss_fb_warp_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ds_fused_loss_fb_warp_bwd": (_i, [_fp] * 9 + [_i] * 4 + [_fp] * 6 + [_fp, _sz, _fp]),
     "ds_loss_step_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ds_loss_step_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "ds_loss_step_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _sz, _fp]),
     "ds_loss_step_fwdbwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "ds_loss_step_fwdbwd": (_i, [_fp] * 7 + [_i] * 4 + [_fp] * 8 + [_fp, _sz, _fp]),
+    "ds_loss_step_fwdbwd": (_i, [_fp] * 7 + [_i] * 4 + [_fp] * 9 + [_fp, _sz, _fp]),
     "ds_smooth_workspace_bytes": (_sz, [_i, _i, _i]),
     "ds_smooth_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp, _sz, _fp]),
     "ds_smooth_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp]),

@@ -1333,9 +1333,20 @@ inline bool fwd_uses_lds(int S, bool idt) { return (idt ? 2 * S : S) <= 6; }
 // sooner (B=12, 192x640: 50.3 -> 47.7 us; gpurun_out/r02_kb1_nby_sweep.txt), and a launch a little over one round is the
 // worst case (+10 %).  So: if the launch cannot reach four rounds, use whole rounds -- the largest chunk count whose
 // workgroups fill k resident rounds exactly or stay just below.
-inline long long pick_chunks(long long per_chunk, long long capacity, int max_nby) {
+// H, min_rows: the image height and the shortest chunk of the regular regime.  A launch that cannot fill even one round
+// with chunks of min_rows is a third regime (pyramid levels, small batches): the chip is mostly empty, the run time is
+// the length of one workgroup's walk (about a microsecond per row), so chunks go down to 4 rows -- the lead-in rows a
+// short chunk repeats cost nothing there (24x80 x 12 targets: 27 -> 9 us for the fused loss kernel).
+inline long long pick_chunks(long long per_chunk, long long capacity, int H, int min_rows) {
+    int max_nby = H / min_rows > 1 ? H / min_rows : 1;
     long long nby = (8 * capacity + per_chunk - 1) / per_chunk;   // about eight rounds
     if (nby <= max_nby) return nby;
+    if (per_chunk * max_nby < capacity) {
+        max_nby = H / 4 > 1 ? H / 4 : 1;
+        nby = capacity / per_chunk;
+        if (nby > max_nby) nby = max_nby;
+        return nby < 1 ? 1 : nby;
+    }
     const double rounds_at_max = (double)per_chunk * max_nby / (double)capacity;
     if (rounds_at_max >= 4.0) return max_nby;
     long long k = (long long)rounds_at_max;
@@ -1353,8 +1364,7 @@ inline Geom make_fwd_lds_geom(int B, int H, int W, int groups) {
     const long long per_cu = groups <= 1 ? 8 : (groups == 2 ? 7 : (groups == 3 ? 5 : (groups == 4 ? 4 : 3)));
     const long long capacity = (long long)simd_count() / 4 * per_cu;
     const long long bands = (long long)B * g.nbx;
-    const int max_nby = H / 12 > 1 ? H / 12 : 1;
-    const long long nby = pick_chunks(bands, capacity, max_nby);
+    const long long nby = pick_chunks(bands, capacity, H, 12);
     g.RB = (H + (int)nby - 1) / (int)nby;
     g.nby = (H + g.RB - 1) / g.RB;
     g.nblocks = B * g.nbx * g.nby;
@@ -1406,8 +1416,7 @@ inline Geom make_bwd_geom(int B, int H, int W) {
     g.nbx = (W + 61) / 62;
     const long long capacity = (long long)simd_count() * 4;  // units resident at once (four waves per SIMD)
     const long long per_chunk = (long long)B * g.nbx * 3;
-    const int max_nby = H / 16 > 1 ? H / 16 : 1;
-    const long long nby = pick_chunks(per_chunk, capacity, max_nby);
+    const long long nby = pick_chunks(per_chunk, capacity, H, 16);
     g.RB = (H + (int)nby - 1) / (int)nby;
     g.nby = (H + g.RB - 1) / g.RB;
     g.nwaves = B * g.nbx * g.nby * 3;
@@ -1421,8 +1430,7 @@ inline Geom make_fb_geom(int B, int H, int W) {
     g.nbx = (W + 61) / 62;
     const long long capacity = simd_count();  // workgroups resident at once: four per CU
     const long long per_chunk = (long long)B * g.nbx;
-    const int max_nby = H / 16 > 1 ? H / 16 : 1;
-    const long long nby = pick_chunks(per_chunk, capacity, max_nby);
+    const long long nby = pick_chunks(per_chunk, capacity, H, 16);
     g.RB = (H + (int)nby - 1) / (int)nby;
     g.nby = (H + g.RB - 1) / g.RB;
     g.nblocks = B * g.nbx * g.nby;

@@ -75,6 +75,27 @@ int ds_warp_identity_fwd(const float* K, const float* Kinv, const float* pose, c
     return ds::warp_and_identity(K, Kinv, pose, depth, src, target, B, S, H, W, warped, idt_loss, (hipStream_t)stream);
 }
 
+size_t ds_fused_loss_fb_warp_bwd_workspace_bytes(int B, int S, int H, int W) {
+    return ds::fused_loss_fb_supported(S) ? ds::fused_loss_fbw_workspace_bytes(B, S, H, W) : 0;
+}
+
+int ds_fused_loss_fb_warp_bwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                              const float* warped, const float* target, const float* idt_loss, const float* g_sums, int B,
+                              int S, int H, int W, float* out_loss, uint8_t* aux, float* sums, float* g_warped,
+                              float* g_depth, float* g_pose, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!sums || !g_pose) return DS_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int wpi = 0;
+    float* pose_partials = nullptr;
+    int rc = ds::fused_loss_fbw_partials(K, Kinv, pose, depth, src, warped, target, idt_loss, g_sums, B, S, H, W, out_loss, aux,
+                                         g_warped, g_depth, workspace, workspace_bytes, &wpi, &pose_partials, st);
+    if (rc != DS_OK) return rc;
+    hipLaunchKernelGGL(step_finalize_kernel, dim3(B + B * S), dim3(64), 0, st, (const float*)workspace, wpi,
+                       1.0 / ((double)H * W), sums, B, (const float*)pose_partials, wpi, g_pose);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
 size_t ds_loss_step_fwdbwd_workspace_bytes(int B, int S, int H, int W) {
     if (B <= 0 || S <= 0 || H < 2 || W < 2) return 0;
     // both sets of partial sums stay live until the single finalize launch at the end
@@ -86,7 +107,7 @@ size_t ds_loss_step_fwdbwd_workspace_bytes(int B, int S, int H, int W) {
 int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
                         const float* target, const float* g_sums, int B, int S, int H, int W, float* warped,
                         float* out_loss, float* idt_loss, uint8_t* aux, float* sums, float* g_warped, float* g_depth,
-                        float* g_pose, void* workspace, size_t workspace_bytes, void* stream) {
+                        float* g_pose, float* g_src, void* workspace, size_t workspace_bytes, void* stream) {
     if (B <= 0 || S <= 0 || (long long)B * S > 65535 || H < 2 || W < 2) return DS_ERR_INVALID_ARG;
     if (!K || !Kinv || !pose || !depth || !src || !target || !warped || !out_loss || !idt_loss || !aux || !sums ||
         !g_warped || !g_depth || !g_pose)
@@ -99,7 +120,20 @@ int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, co
     void* ws_loss = workspace;
     void* ws_warp = (char*)workspace + n_loss;
     int rc, wpi = 0, nblk = 0;
-    if (ds::fused_loss_fb_supported(S)) {
+    if (g_src) {
+        // the image gradient is a scatter into zeroed memory (float atomics, ds_warp_bwd)
+        hipError_t e = hipMemsetAsync(g_src, 0, (size_t)B * S * 3 * H * W * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (ds::fused_loss_fb_supported(S) && g_src) {
+        // with the image gradient: warp + identity map, fused loss forward+backward (d loss / d warped to memory), then
+        // the warp backward kernel that scatters
+        rc = ds::warp_and_identity(K, Kinv, pose, depth, src, target, B, S, H, W, warped, idt_loss, st);
+        if (rc != DS_OK) return rc;
+        rc = ds::fused_loss_fb_partials(warped, target, idt_loss, g_sums, B, S, H, W, out_loss, aux, g_warped, ws_loss, n_loss,
+                                        &wpi, st);
+        if (rc != DS_OK) return rc;
+    } else if (ds::fused_loss_fb_supported(S)) {
         // the warp and the identity map (un-warped sources against the target: nothing of it depends on depth or pose)
         // share one launch; then the forward and the backward of the warped groups in ONE kernel: the backward's window
         // sums are the forward's
@@ -123,7 +157,7 @@ int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, co
         rc = ds_fused_loss_bwd(warped, target, idt_loss, aux, g_sums, B, S, H, W, g_warped, stream);
         if (rc != DS_OK) return rc;
     }
-    rc = ds::warp_bwd_partials(K, Kinv, pose, depth, src, g_warped, B * S, 3, H, W, H, W, g_depth, nullptr, ws_warp,
+    rc = ds::warp_bwd_partials(K, Kinv, pose, depth, src, g_warped, B * S, 3, H, W, H, W, g_depth, g_src, ws_warp,
                                workspace_bytes - n_loss, &nblk, st);
     if (rc != DS_OK) return rc;
     hipLaunchKernelGGL(step_finalize_kernel, dim3(B + B * S), dim3(64), 0, st, (const float*)ws_loss, wpi,

@@ -175,6 +175,7 @@ __device__ __forceinline__ void block_reduce12(float (&gM)[12], float* __restric
 #define DS_BWD_ROWS 8
 #endif
 constexpr int kBwdRows = DS_BWD_ROWS;  // rows per wave: the 12-float pose-gradient wave reduction is paid once per 8 pixels
+constexpr int kBwdRowsSmall = 2;       // for launches too small to fill the chip with kBwdRows
 
 // Image-gradient scatter (IMG).  Direct scatter = 4 device-scope float atomics per pixel and channel: 382 us against 31 us
 // for the rest of the backward at B=12, 192x640.  Collecting the taps in an LDS tile first was measured too: the LDS float
@@ -201,7 +202,10 @@ struct ImgWindow {
     bool live;
 };
 
-template <int C, bool IMG = false>
+// ROWS = rows per wave: kBwdRows for launches that fill the chip, kBwdRowsSmall for small ones (a wave walks its rows one
+// after the other, each a chain of load -> project -> gather -> (scatter): with few workgroups the chain length is the
+// run time; 24x80 x 24 images with the image gradient: 30 us at 8 rows per wave)
+template <int C, bool IMG = false, int ROWS = kBwdRows>
 __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restrict__ K, const float* __restrict__ Kinv,
                                                             const float* __restrict__ pose,
                                                             const float* __restrict__ depth,
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
     const int n = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int bx = blockIdx.x % G.nbx, by = blockIdx.x / G.nbx;
-    const int yb = (by * (kThreads / 64) + wave) * kBwdRows;
+    const int yb = (by * (kThreads / 64) + wave) * ROWS;
     const int x = bx * 64 + lane, xc = min(x, G.W - 1);
     const int Cc = C > 0 ? C : Cdyn;
     const unsigned HW = (unsigned)(G.H * G.W), HsWs = (unsigned)(G.Hs * G.Ws);
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
             win.a[c][0] = win.a[c][1] = win.a[c][2] = win.e[c][0] = win.e[c][1] = win.e[c][2] = 0.f;
     };
 #pragma unroll 2
-    for (int i = 0; i < kBwdRows; ++i) {
+    for (int i = 0; i < ROWS; ++i) {
         const int y = yb + i;
         if (y >= G.H) break;  // wave-uniform
         const unsigned ro = (unsigned)(y * G.W);
@@ -641,7 +645,7 @@ int ds_warp_fwd(const float* K, const float* Kinv, const float* pose, const floa
 
 size_t ds_warp_bwd_workspace_bytes(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
-    const int a = bwd_blocks(H * W), b = warp_tiles(H, W, kBwdRows);  // ds_reproject_bwd / ds_warp_bwd partials
+    const int a = bwd_blocks(H * W), b = warp_tiles(H, W, kBwdRowsSmall);  // ds_reproject_bwd / ds_warp_bwd partials (either tiling)
     return (size_t)N * (a > b ? a : b) * 12 * sizeof(float);
 }
 
@@ -697,18 +701,33 @@ int ds::warp_bwd_partials(const float* K, const float* Kinv, const float* pose, 
         return DS_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < ds_warp_bwd_workspace_bytes(N, H, W)) return DS_ERR_WORKSPACE;
     const WarpGeom G = warp_geom(Hs, Ws, H, W);
-    const int nblk = warp_tiles(H, W, kBwdRows);
+    // small launches (fewer workgroups than would give every SIMD two waves) take the short tiles
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const bool small = (long long)warp_tiles(H, W, kBwdRows) * N < 2ll * cus;
+    const int nblk = warp_tiles(H, W, small ? kBwdRowsSmall : kBwdRows);
     dim3 g(nblk, N), b(kThreads);
     float* partials = (float*)workspace;
-    if (C == 3 && g_src)
-        hipLaunchKernelGGL((warp_bwd_kernel<3, true>), g, b, 0, stream, K, Kinv, pose, depth, src, g_warped, C, G, g_depth,
-                           g_src, partials);
-    else if (C == 3)
-        hipLaunchKernelGGL(warp_bwd_kernel<3>, g, b, 0, stream, K, Kinv, pose, depth, src, g_warped, C, G, g_depth, nullptr,
-                           partials);
-    else
+    if (C == 3 && g_src) {
+        if (small)
+            hipLaunchKernelGGL((warp_bwd_kernel<3, true, kBwdRowsSmall>), g, b, 0, stream, K, Kinv, pose, depth, src, g_warped, C,
+                               G, g_depth, g_src, partials);
+        else
+            hipLaunchKernelGGL((warp_bwd_kernel<3, true>), g, b, 0, stream, K, Kinv, pose, depth, src, g_warped, C, G, g_depth,
+                               g_src, partials);
+    } else if (C == 3) {
+        if (small)
+            hipLaunchKernelGGL((warp_bwd_kernel<3, false, kBwdRowsSmall>), g, b, 0, stream, K, Kinv, pose, depth, src, g_warped,
+                               C, G, g_depth, nullptr, partials);
+        else
+            hipLaunchKernelGGL(warp_bwd_kernel<3>, g, b, 0, stream, K, Kinv, pose, depth, src, g_warped, C, G, g_depth, nullptr,
+                               partials);
+    } else {
         hipLaunchKernelGGL(warp_bwd_kernel<0>, g, b, 0, stream, K, Kinv, pose, depth, src, g_warped, C, G, g_depth, g_src,
                            partials);
+    }
     DS_CHECK_LAUNCH();
     *nblk_out = nblk;
     return DS_OK;

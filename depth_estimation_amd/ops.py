@@ -436,7 +436,7 @@ class _TrainStepEager(torch.autograd.Function):
         gd, gp = torch.empty_like(depth), torch.empty(n, 3, 4, **f32)
         L.check(lib.ds_loss_step_fwdbwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
                                         target.data_ptr(), 0, b, s, h, w, warped.data_ptr(), out.data_ptr(), idt.data_ptr(),
-                                        aux.data_ptr(), sums.data_ptr(), gw.data_ptr(), gd.data_ptr(), gp.data_ptr(),
+                                        aux.data_ptr(), sums.data_ptr(), gw.data_ptr(), gd.data_ptr(), gp.data_ptr(), 0,
                                         wsb.data_ptr(), nb, st), "ds_loss_step_fwdbwd")
         L.check(lib.ds_smooth_batch_fwd(depth.data_ptr(), target.data_ptr(), b, s, 3, h, w, reg.data_ptr(), wsb.data_ptr(), nb,
                                         st), "ds_smooth_batch_fwd")

@@ -154,6 +154,16 @@ int ds_fused_loss_fb(const float* warped, const float* target, const float* idt_
                      int W, float* out_loss, uint8_t* aux, float* sums, float* g_warped, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* ds_fused_loss_fb with the warp's autograd in the same kernel (its fourth wave takes the rows of d loss / d warped from
+ * the loss waves through LDS): everything of a step that follows ds_warp_identity_fwd.  Inputs of ds_fused_loss_fb and
+ * ds_warp_bwd (source size = grid size); outputs out_loss, aux, sums, g_depth (B,S,H,W), g_pose (B,S,3,4) and, if
+ * g_warped is not NULL, d loss / d warped too (otherwise it never reaches memory).  S <= 2. */
+size_t ds_fused_loss_fb_warp_bwd_workspace_bytes(int B, int S, int H, int W);
+int ds_fused_loss_fb_warp_bwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                              const float* warped, const float* target, const float* idt_loss, const float* g_sums, int B,
+                              int S, int H, int W, float* out_loss, uint8_t* aux, float* sums, float* g_warped,
+                              float* g_depth, float* g_pose, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The two halves of a loss step in one call each, on the caller's stream: ds_warp_fwd + ds_fused_loss_fwd, and
  * ds_fused_loss_bwd + ds_warp_bwd (train.py:72-88 and its autograd for B targets; source and grid sizes equal).
  * Arguments as in the four calls; g_warped (B,S,3,H,W) is scratch for the backward.  Same launches, half the calls for a
@@ -174,12 +184,14 @@ int ds_loss_step_bwd(const float* K, const float* Kinv, const float* pose, const
  * NULL for a unit upstream gradient -- what loss.backward() passes for the reference's summed loss (train.py:88,103); a
  * caller with another upstream factor scales g_depth and g_pose by it.  Outputs as in the four calls it replaces;
  * g_warped (B,S,3,H,W) is scratch (for S <= 2 the gradient w.r.t. the warped images passes from the loss kernel's
- * waves to the warp's autograd inside one kernel and the buffer is left untouched).  workspace 16-byte aligned, sized by ds_loss_step_fwdbwd_workspace_bytes. */
+ * waves to the warp's autograd inside one kernel and the buffer is left untouched).  g_src (B,S,3,H,W), optional (NULL
+ * to skip): the gradient w.r.t. the source images through the warp (cleared and accumulated here; float atomics, as in
+ * ds_warp_bwd).  workspace 16-byte aligned, sized by ds_loss_step_fwdbwd_workspace_bytes. */
 size_t ds_loss_step_fwdbwd_workspace_bytes(int B, int S, int H, int W);
 int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
                         const float* target, const float* g_sums, int B, int S, int H, int W, float* warped,
                         float* out_loss, float* idt_loss, uint8_t* aux, float* sums, float* g_warped, float* g_depth,
-                        float* g_pose, void* workspace, size_t workspace_bytes, void* stream);
+                        float* g_pose, float* g_src, void* workspace, size_t workspace_bytes, void* stream);
 
 /* metrics.regularization_term (metrics.py:75-97): depths (N,1,H,W), targets (N,C,H,W) -> value (1)
  * fp32 on device; workspace from ds_smooth_workspace_bytes. */

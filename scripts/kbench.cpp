@@ -161,14 +161,14 @@ int main(int argc, char** argv) {
             warp_bwd(K, Kinv, pose, depth, src, g_warped, N, 3, H, W, H, W, g_depth, g_pose, g_src, w2, n2, s1);
         });
         typedef int (*step_t)(const float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int,
-                              float*, float*, float*, uint8_t*, float*, float*, float*, float*, void*, size_t, void*);
+                              float*, float*, float*, uint8_t*, float*, float*, float*, float*, float*, void*, size_t, void*);
         typedef size_t (*ws4_t)(int, int, int, int);
         auto stepf = (step_t)dlsym(h, "ds_loss_step_fwdbwd");
         auto stepws = (ws4_t)dlsym(h, "ds_loss_step_fwdbwd_workspace_bytes");
         if (stepf && stepws) {
             size_t n3 = stepws(B, S, H, W); void* w3; CK(hipMalloc(&w3, n3));
             double one = wall([&] {
-                int rc = stepf(K, Kinv, pose, depth, src, tgt, nullptr, B, S, H, W, warped, out, idt, aux, sums, g_warped, g_depth, g_pose, w3, n3, s1);
+                int rc = stepf(K, Kinv, pose, depth, src, tgt, nullptr, B, S, H, W, warped, out, idt, aux, sums, g_warped, g_depth, g_pose, g_src, w3, n3, s1);
                 if (rc) { fprintf(stderr, "ds_loss_step_fwdbwd rc=%d\n", rc); exit(1); }
             });
             printf("   ds_loss_step_fwdbwd (one call, merged finalize): %.4f ms per step = %.2f Gpix/s\n", one, (double)N * HW / one / 1e6);

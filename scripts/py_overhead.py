@@ -9,7 +9,7 @@ sc = bench.Scale(de, 12, 2, 192, 640, dev, 0, False)
 s = torch.cuda.Stream(); torch.cuda.set_stream(s); st = s.cuda_stream
 p = lambda t: t.data_ptr()
 args = (p(sc.K), p(sc.Kinv), p(sc.pose), p(sc.depth), p(sc.src), p(sc.tgt), 0, 12, 2, 192, 640, p(sc.warped), p(sc.out), p(sc.idt),
-        p(sc.aux), p(sc.sums), p(sc.g_warped), p(sc.g_depth), p(sc.g_pose), p(sc.ws_step), sc.ws_step_n, st)
+        p(sc.aux), p(sc.sums), p(sc.g_warped), p(sc.g_depth), p(sc.g_pose), 0, p(sc.ws_step), sc.ws_step_n, st)
 fn = sc.lib.ds_loss_step_fwdbwd
 def timed(body, n=300):
     for _ in range(20): body()
