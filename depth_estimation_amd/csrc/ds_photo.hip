@@ -824,6 +824,7 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
     __shared__ float lds_e[2][kK][3][S][64];
     __shared__ float lds_p[3][kK][NP + 1][64];  // per channel wave: centre values and identity loss of the pending rows
     __shared__ float lds_g[WARP ? 2 : 1][kK][3][WARP ? S : 1][WARP ? 64 : 1];  // WARP: rows of d loss / d warped for the 4th wave
+    __shared__ float lds_s[2][WARP ? 64 : 1];                                   // WARP: channel wave 0's per-lane loss sums
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int role = (wave + (int)(blockIdx.x >> 3)) & 3;  // 0..2 = channel, 3 = output wave
     const int lane = threadIdx.x & 63;
@@ -864,7 +865,8 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
             // identity values of this slab's rows and depths of the rows to differentiate, requested before the wait
             float iv[kK], dep[kK][S];
 #pragma unroll
-            for (int k = 0; k < kK; ++k) iv[k] = buf_load_f32(ip, cl, (unsigned)(reflect_idx(y0 - 1 + sl * kK + k, H) * W));
+            for (int k = 0; k < kK; ++k)
+                iv[k] = WARP ? 0.f : buf_load_f32(ip, cl, (unsigned)(reflect_idx(y0 - 1 + sl * kK + k, H) * W));
             if (WARP) {
 #pragma unroll
                 for (int k = 0; k < kK; ++k) {
@@ -876,7 +878,8 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
             }
             __syncthreads();  // the channel waves have filled slab sl & 1 (and the rows of d loss / d warped before it)
             const int buf = sl & 1;
-            if (sl < nslab) {
+            if (!WARP && sl < nslab) {   // WARP: channel wave 0 writes out / argmin and keeps the sums (this wave is the
+                                         // workgroup's critical path there)
 #pragma unroll
                 for (int k = 0; k < kK; ++k) {
                     const int y = y0 - 1 + sl * kK + k;
@@ -955,11 +958,13 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
                 }
             }
         }
-        sum_ratio = wave_sum(sum_ratio);
-        sum_out = wave_sum(sum_out);
-        if (lane == 0) {
-            P.wave_partials[2 * wg + 0] = sum_ratio;
-            P.wave_partials[2 * wg + 1] = sum_out;
+        if (!WARP) {
+            sum_ratio = wave_sum(sum_ratio);
+            sum_out = wave_sum(sum_out);
+            if (lane == 0) {
+                P.wave_partials[2 * wg + 0] = sum_ratio;
+                P.wave_partials[2 * wg + 1] = sum_out;
+            }
         }
         if (WARP) {
             const int per_image = P.nbx * P.nby, slot = by * P.nbx + bx;
@@ -1094,6 +1099,8 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
     }
 
     float wraw[NP], wiv;  // centre values / identity loss of the window row a raw row has just finished
+    // WARP, channel wave 0: the sums the output wave keeps otherwise -- in LDS (two registers more and the kernel spills)
+    if (WARP && c == 0) lds_s[0][lane] = lds_s[1][lane] = 0.f;
     // lead-in: rows y0-2 and y0-1 only feed the partial sums
     DS_FB_RAW_ROW(y0 - 2)
     DS_FB_RAW_ROW(y0 - 1)
@@ -1129,14 +1136,20 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
             for (int g = 0; g < S; ++g)
                 E[g] = div3((lds_e[buf][k][0][g][lane] + lds_e[buf][k][1][g][lane]) + lds_e[buf][k][2][g][lane]);
             int bi = 0;
-            {
-                float best = E[0];
+            float best = E[0];
 #pragma unroll
-                for (int g = 1; g < S; ++g)
-                    if (E[g] < best) { best = E[g]; bi = g; }
+            for (int g = 1; g < S; ++g)
+                if (E[g] < best) { best = E[g]; bi = g; }
+            const float ivk = lds_p[c][k][NP][lane];
+            if (WARP && c == 0 && lane_out && j >= y0 && j < yend) {   // the output wave's part (see there)
+                const size_t o = (size_t)b * HW + (size_t)j * W + col;
+                P.out[o] = best;
+                P.aux[o] = (uint8_t)bi;
+                lds_s[0][lane] += best / expf(ivk + 1e-6f);  // train.py:88
+                lds_s[1][lane] += best;                      // train.py:92
             }
             // gradient weight of this row's pixels: d loss / d out(p)
-            const float gw = gscale * __builtin_amdgcn_exp2f((lds_p[c][k][NP][lane] + 1e-6f) * -1.4426950408889634f);
+            const float gw = gscale * __builtin_amdgcn_exp2f((ivk + 1e-6f) * -1.4426950408889634f);
             const bool win_exists = col_exists && j >= 0 && j < H;
             float bx_ = q.ax[0], bxx = q.axx[0], bxy = q.axy[0];
 #pragma unroll
@@ -1201,7 +1214,16 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
         }
     }
 #undef DS_FB_RAW_ROW
-    if (WARP) __syncthreads();  // the fourth wave's last iteration: it takes the rows of the last slab after this barrier
+    if (WARP) {
+        __syncthreads();  // the fourth wave's last iteration: it takes the rows of the last slab after this barrier
+        if (c == 0) {
+            const float r0 = wave_sum(lds_s[0][lane]), r1 = wave_sum(lds_s[1][lane]);
+            if (lane == 0) {
+                P.wave_partials[2 * wg + 0] = r0;
+                P.wave_partials[2 * wg + 1] = r1;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
