@@ -99,9 +99,13 @@ def check(rc: int, what: str) -> None:
 
 
 def stream() -> int:
-    """Raw handle of torch's current stream on the current device (torch.cuda.current_stream() builds a Python object
-    per call, ~12 us each: four of them were a tenth of a small loss step)."""
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    """Raw handle of torch's current stream on the current device.  torch.cuda.current_stream() builds a Python object
+    per call (~12 us each: four of them were a tenth of a small loss step), so the raw lookup torch itself uses is
+    preferred where this torch build has it; the public call is the fallback."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except AttributeError:
+        return torch.cuda.current_stream().cuda_stream
 
 
 def dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -133,10 +137,18 @@ def ptr(t) -> int:
 
 class Workspace:
     """Scratch buffer per (device, stream), reused across calls (kernels never allocate); calls on one stream are
-    ordered, calls on different streams must not share partial sums."""
+    ordered, calls on different streams must not share partial sums.  A buffer only grows; `release()` drops them all
+    (e.g. after a one-off call at a much larger size, or when streams come and go)."""
 
     def __init__(self):
         self._buf = {}
+
+    def release(self) -> None:
+        """Forget every buffer (torch frees them once the kernels already queued on their streams have run)."""
+        self._buf.clear()
+
+    def nbytes(self) -> int:
+        return sum(b.numel() for b in self._buf.values())
 
     def get(self, nbytes: int, device: torch.device) -> torch.Tensor:
         key = (device.index, stream())
