@@ -219,17 +219,24 @@ struct Cam {            // wave-uniform: the compiler keeps these in SGPRs
     float M[12];        // pose (3,4)
 };
 
+// A value every lane of the wave holds alike, pinned to a scalar register: where the compiler cannot prove that a
+// uniform-address load is not clobbered (kernels that also store) it loads through the vector path and the 30 floats of
+// a camera sit in VGPRs -- in photo_fb_kernel that was 60 of the 128 a wave has.
+__device__ __forceinline__ float wave_uniform(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
 __device__ __forceinline__ void load_cam(Cam& c, const float* __restrict__ K4, const float* __restrict__ Kinv4,
                                          const float* __restrict__ pose) {
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            c.K[3 * j + k] = K4[4 * j + k];
-            c.Kinv[3 * j + k] = Kinv4[4 * j + k];
+            c.K[3 * j + k] = wave_uniform(K4[4 * j + k]);
+            c.Kinv[3 * j + k] = wave_uniform(Kinv4[4 * j + k]);
         }
 #pragma unroll
-    for (int i = 0; i < 12; ++i) c.M[i] = pose[i];
+    for (int i = 0; i < 12; ++i) c.M[i] = wave_uniform(pose[i]);
 }
 
 struct Proj {

@@ -825,6 +825,7 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
     __shared__ float lds_p[3][kK][NP + 1][64];  // per channel wave: centre values and identity loss of the pending rows
     __shared__ float lds_g[WARP ? 2 : 1][kK][3][WARP ? S : 1][WARP ? 64 : 1];  // WARP: rows of d loss / d warped for the 4th wave
     __shared__ float lds_s[2][WARP ? 64 : 1];                                   // WARP: channel wave 0's per-lane loss sums
+    __shared__ float lds_w[WARP ? kK : 1][WARP ? S : 1][7][WARP ? 64 : 1];      // WARP: the 4th wave's per-chain state across the barrier
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int role = (wave + (int)(blockIdx.x >> 3)) & 3;  // 0..2 = channel, 3 = output wave
     const int lane = threadIdx.x & 63;
@@ -861,16 +862,62 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
         }
         const float sxg = WARP ? (P.G.w1 * 0.5f) * (2.0f * P.G.rw1) : 0.f, syg = WARP ? (P.G.h1 * 0.5f) * (2.0f * P.G.rh1) : 0.f;
         const int niter = WARP ? nslab + 1 : nslab;
+        // WARP: the gathers of a slab's rows do not depend on the channel waves -- only the rows of d loss / d warped do.  So
+        // the projection, the taps and the 6 gathers of all kK x S (row, source) chains are issued BEFORE the barrier and
+        // are back when the channel waves arrive; after it only the arithmetic is left.  (One chain at a time after the
+        // barrier, as round 2 first had it, made this wave the workgroup's critical path: four dependent memory round
+        // trips per slab.)  The depths are requested one slab earlier still.
+        float dep[kK][S];
+        if (WARP) {
+#pragma unroll
+            for (int k = 0; k < kK; ++k)
+#pragma unroll
+                for (int s = 0; s < S; ++s) dep[k][s] = 1.0f;
+        }
         for (int sl = 0; sl < niter; ++sl) {
-            // identity values of this slab's rows and depths of the rows to differentiate, requested before the wait
-            float iv[kK], dep[kK][S];
+            // identity values of this slab's rows, requested before the wait
+            float iv[kK];
 #pragma unroll
             for (int k = 0; k < kK; ++k)
                 iv[k] = WARP ? 0.f : buf_load_f32(ip, cl, (unsigned)(reflect_idx(y0 - 1 + sl * kK + k, H) * W));
+            float2_t top_[WARP ? kK : 1][WARP ? S : 1][3], bot_[WARP ? kK : 1][WARP ? S : 1][3];
             if (WARP) {
+                if (sl >= 1) {
+#pragma unroll
+                    for (int k = 0; k < kK; ++k) {
+                        const int t = y0 - 2 + (sl - 1) * kK + k;   // output row of window row y0-1 + (sl-1)*kK + k
+                        if (t < y0 || t >= yend) continue;          // uniform
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            Proj pr;
+                            float rz;
+                            Tap tp;
+                            project_pixel_lean(cam[s], (float)xc, (float)t, dep[k][s], pr, rz);
+                            make_tap(pr.u, pr.v, P.G, tp);
+                            const rsrc_t sp = make_rsrc(P.src + (size_t)(b * S + s) * 3 * HW);
+#pragma unroll
+                            for (int ch3 = 0; ch3 < 3; ++ch3) {
+                                top_[k][s][ch3] = buf_load_f32x2(sp, tp.o_top, ch3 * HsWs * 4u);
+                                bot_[k][s][ch3] = buf_load_f32x2(sp, tp.o_bot, ch3 * HsWs * 4u);
+                            }
+                            // what the arithmetic after the barrier needs of this chain goes through LDS (own lane's slot, no
+                            // synchronisation): in registers the four chains' state spills (53 VGPRs)
+                            const int flags = (tp.shift ? 1 : 0) | ((tp.ixu > 0.0f && tp.ixu < P.G.w1) ? 2 : 0) |
+                                              ((tp.iyu > 0.0f && tp.iyu < P.G.h1) ? 4 : 0) | ((fabsf(pr.q[2]) < 1e-6f) ? 8 : 0);
+                            lds_w[k][s][0][lane] = tp.wx;
+                            lds_w[k][s][1][lane] = tp.ny;
+                            lds_w[k][s][2][lane] = __int_as_float(flags);
+                            lds_w[k][s][3][lane] = pr.u;
+                            lds_w[k][s][4][lane] = pr.v;
+                            lds_w[k][s][5][lane] = rz;
+                            lds_w[k][s][6][lane] = dep[k][s];
+                        }
+                    }
+                }
+                // depths of the rows the NEXT iteration differentiates
 #pragma unroll
                 for (int k = 0; k < kK; ++k) {
-                    const int t = min(max(y0 - 2 + (sl - 1) * kK + k, 0), H - 1);
+                    const int t = min(max(y0 - 2 + sl * kK + k, 0), H - 1);
 #pragma unroll
                     for (int s = 0; s < S; ++s)
                         dep[k][s] = buf_load_f32(make_rsrc(P.depth + (size_t)(b * S + s) * HW), xb, (unsigned)(t * W));
@@ -878,8 +925,7 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
             }
             __syncthreads();  // the channel waves have filled slab sl & 1 (and the rows of d loss / d warped before it)
             const int buf = sl & 1;
-            if (!WARP && sl < nslab) {   // WARP: channel wave 0 writes out / argmin and keeps the sums (this wave is the
-                                         // workgroup's critical path there)
+            if (!WARP && sl < nslab) {   // WARP: channel wave 0 writes out / argmin and keeps the sums
 #pragma unroll
                 for (int k = 0; k < kK; ++k) {
                     const int y = y0 - 1 + sl * kK + k;
@@ -903,41 +949,46 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
             }
             if (WARP && sl >= 1) {
                 const int gbuf = (sl - 1) & 1;
+                float fxl = (float)xc;
+                asm volatile("" : "+v"(fxl));   // a value of its own: the ray is formed again, not kept across the barrier
 #pragma unroll
                 for (int k = 0; k < kK; ++k) {
-                    const int t = y0 - 2 + (sl - 1) * kK + k;   // output row of window row y0-1 + (sl-1)*kK + k
+                    const int t = y0 - 2 + (sl - 1) * kK + k;
                     if (t < y0 || t >= yend) continue;          // uniform
 #pragma unroll
-                    for (int s = 0; s < S; ++s) {   // one source at a time: with two in flight the kernel spills (+13 % / +22 % run
-                                                    // time), with three waves per SIMD to make room +22 % / +8 %
-                                                    // (profiles/r02_kb4_warp_wave_variants.txt)
-                        Proj pr;
-                        float rz;
-                        Tap tp;
-                        float2_t top[3], bot[3];
-                        project_pixel_lean(cam[s], (float)xc, (float)t, dep[k][s], pr, rz);
-                        make_tap(pr.u, pr.v, P.G, tp);
-                        const rsrc_t sp = make_rsrc(P.src + (size_t)(b * S + s) * 3 * HW);
+                    for (int s = 0; s < S; ++s) {
+                        const float wx = lds_w[k][s][0][lane], ny = lds_w[k][s][1][lane];
+                        const int flags = __float_as_int(lds_w[k][s][2][lane]);
+                        const float pu = lds_w[k][s][3][lane], pv = lds_w[k][s][4][lane], rz = lds_w[k][s][5][lane];
+                        const float d = lds_w[k][s][6][lane];
+                        const float ex = 1.0f - wx, sy = 1.0f - ny;   // as make_tap forms them
+                        const bool shift = flags & 1;
+                        float pc[3], pP[3];                            // as project_pixel_lean forms them
 #pragma unroll
-                        for (int ch3 = 0; ch3 < 3; ++ch3) {
-                            top[ch3] = buf_load_f32x2(sp, tp.o_top, ch3 * HsWs * 4u);
-                            bot[ch3] = buf_load_f32x2(sp, tp.o_bot, ch3 * HsWs * 4u);
+                        for (int j = 0; j < 3; ++j) {
+                            float acc = fxl * cam[s].Kinv[3 * j + 0];
+                            acc = fmaf((float)t, cam[s].Kinv[3 * j + 1], acc);
+                            acc = fmaf(1.0f, cam[s].Kinv[3 * j + 2], acc);
+                            pc[j] = acc;
+                            pP[j] = acc * d;
                         }
+                        const float2_t* top = top_[k][s];
+                        const float2_t* bot = bot_[k][s];
                         float gix = 0.f, giy = 0.f;
 #pragma unroll
                         for (int ch3 = 0; ch3 < 3; ++ch3) {
                             const float gc = lane_out ? lds_g[gbuf][k][ch3][s][lane] : 0.0f;
                             const float2_t a = top[ch3], bb = bot[ch3];
-                            const float nw = tp.shift ? a.y : a.x, ne = a.y, sw = tp.shift ? bb.y : bb.x, se = bb.y;
-                            gix = fmaf(gc, fmaf(ne - nw, tp.sy, (se - sw) * tp.ny), gix);
-                            giy = fmaf(gc, fmaf(sw - nw, tp.ex, (se - ne) * tp.wx), giy);
+                            const float nw = shift ? a.y : a.x, ne = a.y, sw = shift ? bb.y : bb.x, se = bb.y;
+                            gix = fmaf(gc, fmaf(ne - nw, sy, (se - sw) * ny), gix);
+                            giy = fmaf(gc, fmaf(sw - nw, ex, (se - ne) * wx), giy);
                         }
                         // torch grid_sampler_2d backward: zero on or outside the border of the un-clipped coordinate
-                        gix = (tp.ixu > 0.0f && tp.ixu < P.G.w1) ? gix * sxg : 0.0f;
-                        giy = (tp.iyu > 0.0f && tp.iyu < P.G.h1) ? giy * syg : 0.0f;
+                        gix = (flags & 2) ? gix * sxg : 0.0f;
+                        giy = (flags & 4) ? giy * syg : 0.0f;
                         if (!lane_out) gix = giy = 0.0f;   // halo lanes and lanes beyond the image
                         const float gq0 = gix * rz, gq1 = giy * rz;
-                        const float gq2 = (fabsf(pr.q[2]) < 1e-6f) ? 0.0f : -(fmaf(pr.u, gix, pr.v * giy)) * rz;
+                        const float gq2 = (flags & 8) ? 0.0f : -(fmaf(pu, gix, pv * giy)) * rz;
                         float gT[3], gP[3];
 #pragma unroll
                         for (int q = 0; q < 3; ++q)
@@ -945,12 +996,12 @@ __global__ __launch_bounds__(64 * kFwdWaves, S <= 2 ? 4 : 3) void photo_fb_kerne
 #pragma unroll
                         for (int q = 0; q < 3; ++q)
                             gP[q] = fmaf(cam[s].M[8 + q], gT[2], fmaf(cam[s].M[4 + q], gT[1], cam[s].M[q] * gT[0]));
-                        const float gd = fmaf(pr.c[2], gP[2], fmaf(pr.c[1], gP[1], pr.c[0] * gP[0]));
+                        const float gd = fmaf(pc[2], gP[2], fmaf(pc[1], gP[1], pc[0] * gP[0]));
 #pragma unroll
                         for (int j2 = 0; j2 < 3; ++j2) {
-                            gM[s][4 * j2 + 0] = fmaf(gT[j2], pr.P[0], gM[s][4 * j2 + 0]);
-                            gM[s][4 * j2 + 1] = fmaf(gT[j2], pr.P[1], gM[s][4 * j2 + 1]);
-                            gM[s][4 * j2 + 2] = fmaf(gT[j2], pr.P[2], gM[s][4 * j2 + 2]);
+                            gM[s][4 * j2 + 0] = fmaf(gT[j2], pP[0], gM[s][4 * j2 + 0]);
+                            gM[s][4 * j2 + 1] = fmaf(gT[j2], pP[1], gM[s][4 * j2 + 1]);
+                            gM[s][4 * j2 + 2] = fmaf(gT[j2], pP[2], gM[s][4 * j2 + 2]);
                             gM[s][4 * j2 + 3] += gT[j2];
                         }
                         if (lane_out) P.g_depth[(size_t)(b * S + s) * HW + (size_t)t * W + col] = gd;
