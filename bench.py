@@ -314,6 +314,8 @@ def main():
     ap.add_argument("--pipelined", type=int, default=3,
                     help="also report the un-joined variant: this many independent sub-batches, each on its own HIP "
                          "stream, never joined between steps (0 = skip); never the headline")
+    ap.add_argument("--spin-up", type=float, default=SPIN_UP_S,
+                    help="seconds of untimed steps before the warm-up (device out of its idle power state); 0 for profiler passes")
     ap.add_argument("--dry", action="store_true", help="launcher / rendezvous check on the CPU (gloo), no kernels")
     args = ap.parse_args()
 
@@ -365,7 +367,7 @@ def main():
     # more, profiles/r02_warmup_sensitivity.txt).  Untimed, the same steps, SPIN_UP_S seconds; then the W warm-up steps
     # and the K timed steps of the contract.
     s0 = time.perf_counter()
-    while time.perf_counter() - s0 < SPIN_UP_S:
+    while time.perf_counter() - s0 < args.spin_up:
         for _ in range(50):
             step()
         torch.cuda.synchronize()
@@ -483,7 +485,7 @@ def main():
                        "metrics_reduce": bool(wl.get("metrics", False)),
                        "launch": "eager, whole batch on one stream, steps ordered (joined); " +
                                  ("one C-ABI call per pyramid level (ds_loss_step_fwdbwd)" if wl["scales"] > 1 else "one C-ABI call per step (ds_loss_step_fwdbwd)"),
-                       "parallelism": f"batch-sharded x{world}, no collective", "spin_up_s": SPIN_UP_S},
+                       "parallelism": f"batch-sharded x{world}, no collective", "spin_up_s": args.spin_up},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(hbm_frac, 4), "traffic": traffic,
                          "alg_bytes_per_launch": sc0.alg_bytes[dom], "avg_ms": round(kern_ms[dom], 5),

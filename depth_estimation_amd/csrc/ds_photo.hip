@@ -87,6 +87,15 @@ __device__ __forceinline__ float roll(Roll& s, float L, float C, float R) {
     return w;
 }
 
+struct WarpIdtParams {
+    const float* K; const float* Kinv; const float* pose; const float* depth; const float* src; float* warped;
+    ds::WarpGeom G;
+    int tiles_per_image;   // warp tiles per image
+    int n_warp, n_loss;    // workgroups of each kind
+    int groups_warp, groups_total;
+    int warp_first;        // 1: all warp groups, then all loss groups; 0: interleaved in proportion
+};
+
 constexpr int kLdsRow = 68;  // 64 columns + left/right halo column (+2 pad)
 
 // One workgroup = four waves on one band of 64 adjacent columns (all of them useful), walking down a row chunk
@@ -110,8 +119,11 @@ constexpr int kLdsRow = 68;  // 64 columns + left/right halo column (+2 pad)
 constexpr int kFwdWaves = 4;
 
 // bid / nblk: this workgroup's index in the list of the launch's loss workgroups (the block index in a plain launch)
-template <int S, bool IDT>
-__device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid, int nblk) {
+// EW: the E wave -- idle nine tenths of the time -- also runs ds_warp_fwd for the band's rows (Q: the warp's arguments),
+// software-pipelined around the slab barriers so that no gather is waited for: a unit = 2 rows x S sources is projected
+// and its 6 gathers per (row, source) issued, the previous unit is blended and stored while they fly.
+template <int S, bool IDT, bool EW = false>
+__device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid, int nblk, const WarpIdtParams* Q = nullptr) {
     constexpr int G = IDT ? 2 * S : S;
     constexpr int NP = 1 + G;
     constexpr int kK = G <= 4 ? 4 : 2;  // rows per barrier (slab = 2 * kK * 3 * G * 256 B of LDS)
@@ -132,10 +144,85 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
         const bool lane_out = col < W;
         float sum_ratio = 0.f, sum_out = 0.f;
         const int nrows = yend - y0;
+        // EW: the warp of this band's rows (ds_warp_fwd's arithmetic: project_pixel_lean, make_tap, corner pairs)
+        constexpr int UR = 2;                 // rows per unit; kK = 2 units per slab
+        constexpr int SW = EW ? (S >= 2 ? S - 1 : 1) : 1;   // S >= 2: the last source is warped by the channel waves (below)
+        constexpr bool EWX = EW && !(DS_EXP & 8);
+        static_assert(!EW || kK == 2 * UR, "two warp units per slab");
+        Cam cam[SW];
+        float2_t top[UR][SW][3], bot[UR][SW][3];
+        float wgt[UR][SW][4], dnx[UR][SW];
+        const int xc = min(col, W - 1);
+        const unsigned xb = (unsigned)xc * 4u, uHW = (unsigned)HW;
+        const int nunits = (nrows + UR - 1) / UR;
+        auto load_depth = [&](int u) {
+#pragma unroll
+            for (int i = 0; i < UR; ++i) {
+                const int row = min(y0 + u * UR + i, H - 1);
+#pragma unroll
+                for (int s = 0; s < SW; ++s)
+                    dnx[i][s] = buf_load_f32(make_rsrc(Q->depth + (size_t)(b * S + s) * HW), xb, (unsigned)(row * W));
+            }
+        };
+        auto issue_unit = [&](int u) {
+#pragma unroll
+            for (int i = 0; i < UR; ++i) {
+                const int row = min(y0 + u * UR + i, H - 1);
+#pragma unroll
+                for (int s = 0; s < SW; ++s) {
+                    Proj pr;
+                    float rz;
+                    Tap tp;
+                    project_pixel_lean(cam[s], (float)xc, (float)row, dnx[i][s], pr, rz);
+                    make_tap(pr.u, pr.v, Q->G, tp);
+                    const rsrc_t sp = make_rsrc(Q->src + (size_t)(b * S + s) * 3 * HW);
+#pragma unroll
+                    for (int c3 = 0; c3 < 3; ++c3) {
+                        top[i][s][c3] = buf_load_f32x2(sp, tp.o_top, c3 * uHW * 4u);
+                        bot[i][s][c3] = buf_load_f32x2(sp, tp.o_bot, c3 * uHW * 4u);
+                    }
+                    wgt[i][s][0] = tp.wa_t; wgt[i][s][1] = tp.wb_t; wgt[i][s][2] = tp.wa_b; wgt[i][s][3] = tp.wb_b;
+                }
+            }
+        };
+        auto finish_unit = [&](int u) {
+#pragma unroll
+            for (int i = 0; i < UR; ++i) {
+                const int row = y0 + u * UR + i;
+                if (row >= yend) continue;   // uniform
+#pragma unroll
+                for (int s = 0; s < SW; ++s) {
+                    const rsrc_t op = make_rsrc(Q->warped + (size_t)(b * S + s) * 3 * HW);
+#pragma unroll
+                    for (int c3 = 0; c3 < 3; ++c3) {
+                        float acc = top[i][s][c3].x * wgt[i][s][0];
+                        acc = fmaf(top[i][s][c3].y, wgt[i][s][1], acc);
+                        acc = fmaf(bot[i][s][c3].x, wgt[i][s][2], acc);
+                        acc = fmaf(bot[i][s][c3].y, wgt[i][s][3], acc);
+                        if (lane_out) buf_store_f32(acc, op, (unsigned)col * 4u, (c3 * uHW + (unsigned)(row * W)) * 4u);
+                    }
+                }
+            }
+        };
+        if (EWX) {
+#pragma unroll
+            for (int s = 0; s < SW; ++s) load_cam(cam[s], Q->K, Q->Kinv, Q->pose + 12 * (b * S + s));
+            load_depth(0);
+            issue_unit(0);
+            if (nunits > 1) load_depth(1);
+        }
+        int u = 0;
         for (int k0 = 0; k0 < nrows; k0 += kK) {
 #if !(DS_EXP & 2)
             __syncthreads();  // the channel waves have filled slab (k0 / kK) & 1
 #endif
+            if (EWX) {
+                finish_unit(u);
+                if (u + 1 < nunits) {
+                    issue_unit(u + 1);
+                    if (u + 2 < nunits) load_depth(u + 2);
+                }
+            }
             const int buf = (k0 / kK) & 1;
             const int kn = min(kK, nrows - k0);
             for (int k = 0; k < kn; ++k) {
@@ -167,6 +254,14 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
                         sum_out += best;                        // train.py:92
                     }
                 }
+            }
+            if (EWX) {
+                if (u + 1 < nunits) finish_unit(u + 1);
+                if (u + 2 < nunits) {
+                    issue_unit(u + 2);
+                    if (u + 3 < nunits) load_depth(u + 3);
+                }
+                u += 2;
             }
         }
         if (IDT) {
@@ -244,6 +339,50 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
         Xp[g] = 0.f;
     }
 
+    // EW, S >= 2: the E wave warps sources 0..S-2; the last source's rows are shared out over the three channel waves (row
+    // k of the chunk to wave k % 3) -- with all S sources the E wave had more instructions per slab than a channel wave
+    // and set the workgroup's pace.  One (row, source) chain per wave in flight for three row steps: project, tap, 6
+    // gathers at step k; blend and store at step k + 3.
+    constexpr bool EWC = EW && S >= 2 && !(DS_EXP & 8);
+    constexpr int s1 = S - 1;
+    Cam camw;
+    float2_t wtop[3], wbot[3];
+    float wwg[4], wdn = 1.0f;
+    int wpend = -1, kmod = 0;
+    const int xcw = min(col, W - 1);
+    if (EWC) {
+        load_cam(camw, Q->K, Q->Kinv, Q->pose + 12 * (b * S + s1));
+        if (y0 + c < yend) wdn = buf_load_f32(make_rsrc(Q->depth + (size_t)(b * S + s1) * HW), (unsigned)xcw * 4u, (unsigned)((y0 + c) * W));
+    }
+    auto warp_finish = [&]() {
+        const rsrc_t op = make_rsrc(Q->warped + (size_t)(b * S + s1) * 3 * HW);
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+            float acc = wtop[c3].x * wwg[0];
+            acc = fmaf(wtop[c3].y, wwg[1], acc);
+            acc = fmaf(wbot[c3].x, wwg[2], acc);
+            acc = fmaf(wbot[c3].y, wwg[3], acc);
+            if (col < W) buf_store_f32(acc, op, (unsigned)col * 4u, (c3 * uHW + (unsigned)(wpend * W)) * 4u);
+        }
+    };
+    auto warp_issue = [&](int row) {
+        Proj pr;
+        float rz;
+        Tap tpw;
+        project_pixel_lean(camw, (float)xcw, (float)row, wdn, pr, rz);
+        make_tap(pr.u, pr.v, Q->G, tpw);
+        const rsrc_t spw = make_rsrc(Q->src + (size_t)(b * S + s1) * 3 * HW);
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+            wtop[c3] = buf_load_f32x2(spw, tpw.o_top, c3 * uHW * 4u);
+            wbot[c3] = buf_load_f32x2(spw, tpw.o_bot, c3 * uHW * 4u);
+        }
+        wwg[0] = tpw.wa_t; wwg[1] = tpw.wb_t; wwg[2] = tpw.wa_b; wwg[3] = tpw.wb_b;
+        wpend = row;
+        if (row + 3 < yend)
+            wdn = buf_load_f32(make_rsrc(Q->depth + (size_t)(b * S + s1) * HW), (unsigned)xcw * 4u, (unsigned)((row + 3) * W));
+    };
+
     float pend[NP], pendh[NP], cL[NP], cC[NP], cR[NP];
     issue(y0 - 1, pend, pendh);
     exchange(pend, pendh, cL, cR);
@@ -272,6 +411,13 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
         }
         if (r > y0) {
             const int k = r - y0 - 1;  // index of the finished output row inside the chunk
+            if (EWC) {
+                if (kmod == c) {   // uniform
+                    if (wpend >= 0) warp_finish();
+                    warp_issue(y0 + k);
+                }
+                kmod = kmod == 2 ? 0 : kmod + 1;
+            }
             TgtStats ts;
             target_stats(ay, ayy, ts);
             float (*slab)[G][64] = lds_e[(k / kK) & 1][k % kK];
@@ -295,6 +441,7 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
             cR[p] = nR[p];
         }
     }
+    if (EWC && wpend >= 0) warp_finish();
 }
 
 template <int S, bool IDT>
@@ -312,17 +459,13 @@ __global__ __launch_bounds__(64 * kFwdWaves, (IDT ? 2 * S : S) > 4 ? 3 : 4) void
 // 100.2 % / 98.1 %.  A launch of a few rounds gains from the missing kernel boundary only (the loss workgroups start
 // while the last warp tiles drain); a long one gains a little from sharing.  So: warp first for small launches,
 // interleaved for large ones.
-struct WarpIdtParams {
-    const float* K; const float* Kinv; const float* pose; const float* depth; const float* src; float* warped;
-    ds::WarpGeom G;
-    int tiles_per_image;   // warp tiles per image
-    int n_warp, n_loss;    // workgroups of each kind
-    int groups_warp, groups_total;
-    int warp_first;        // 1: all warp groups, then all loss groups; 0: interleaved in proportion
-};
 
-template <int S>
+template <int S, bool EW>
 __global__ __launch_bounds__(64 * kFwdWaves, 4) void warp_idt_kernel(WarpIdtParams Q, PhotoFwdParams P) {
+    if (EW) {   // every workgroup is a loss workgroup whose E wave warps the band's rows
+        photo_fwd_body<S, false, true>(P, (int)blockIdx.x, (int)gridDim.x, &Q);
+        return;
+    }
     const int grp = (int)(blockIdx.x >> 3), x = (int)(blockIdx.x & 7);
     // number of warp groups among the first g groups: floor(g * groups_warp / groups_total)
     int before, upto;
@@ -1429,12 +1572,13 @@ inline long long pick_chunks(long long per_chunk, long long capacity, int H, int
     return nby < 1 ? 1 : nby;
 }
 
-inline Geom make_fwd_lds_geom(int B, int H, int W, int groups) {
+inline Geom make_fwd_lds_geom(int B, int H, int W, int groups, int per_cu_given = 0) {
     Geom g;
     g.nbx = (W + 63) / 64;
     // workgroups resident at once: one wave per SIMD each, as many per CU as the VGPR count of the variant allows
     // (111 VGPRs at G = 4: four; 68 at G = 2: seven)
-    const long long per_cu = groups <= 1 ? 8 : (groups == 2 ? 7 : (groups == 3 ? 5 : (groups == 4 ? 4 : 3)));
+    const long long per_cu = per_cu_given > 0 ? per_cu_given :
+                             groups <= 1 ? 8 : (groups == 2 ? 7 : (groups == 3 ? 5 : (groups == 4 ? 4 : 3)));
     const long long capacity = (long long)simd_count() / 4 * per_cu;
     const long long bands = (long long)B * g.nbx;
     const long long nby = pick_chunks(bands, capacity, H, 12);
@@ -1669,7 +1813,11 @@ int ds::warp_and_identity(const float* K, const float* Kinv, const float* pose, 
     P.tgt_stride_b = 3 * HW;
     P.B = B; P.H = H; P.W = W;
     P.out = idt_loss; P.aux = nullptr;
-    const Geom gm = make_fwd_geom(B, H, W, S, false);
+    // S <= 2: every workgroup is a loss workgroup whose waves also warp (55 / 95 VGPRs at S = 1 / 2: eight / five per CU);
+    // S > 2: warp workgroups and loss workgroups side by side in one launch
+    static const int ew_per_cu = getenv("DS_EW_PERCU") ? atoi(getenv("DS_EW_PERCU")) : 0;
+    const bool ew = S <= 2;
+    const Geom gm = ew ? make_fwd_lds_geom(B, H, W, S, ew_per_cu > 0 ? ew_per_cu : (S == 1 ? 8 : 5)) : make_fwd_geom(B, H, W, S, false);
     P.nbx = gm.nbx; P.nby = gm.nby; P.RB = gm.RB;
     WarpIdtParams Q{};
     Q.K = K; Q.Kinv = Kinv; Q.pose = pose; Q.depth = depth; Q.src = src; Q.warped = warped;
@@ -1681,12 +1829,21 @@ int ds::warp_and_identity(const float* K, const float* Kinv, const float* pose, 
     Q.groups_warp = (Q.n_warp + 7) / 8;
     Q.groups_total = Q.groups_warp + (Q.n_loss + 7) / 8;
     Q.warp_first = (long long)Q.n_loss <= 7ll * simd_count() ? 1 : 0;   // fewer than ~4 resident rounds of loss workgroups
-    const dim3 grid(8 * Q.groups_total), block(64 * kFwdWaves);
-    switch (S) {
-        case 1: hipLaunchKernelGGL((warp_idt_kernel<1>), grid, block, 0, stream, Q, P); break;
-        case 2: hipLaunchKernelGGL((warp_idt_kernel<2>), grid, block, 0, stream, Q, P); break;
-        case 3: hipLaunchKernelGGL((warp_idt_kernel<3>), grid, block, 0, stream, Q, P); break;
-        default: hipLaunchKernelGGL((warp_idt_kernel<4>), grid, block, 0, stream, Q, P); break;
+    const dim3 block(64 * kFwdWaves);
+    if (ew) {
+        const dim3 grid(Q.n_loss);
+        switch (S) {
+            case 1: hipLaunchKernelGGL((warp_idt_kernel<1, true>), grid, block, 0, stream, Q, P); break;
+            default: hipLaunchKernelGGL((warp_idt_kernel<2, true>), grid, block, 0, stream, Q, P); break;
+        }
+    } else {
+        const dim3 grid(8 * Q.groups_total);
+        switch (S) {
+            case 1: hipLaunchKernelGGL((warp_idt_kernel<1, false>), grid, block, 0, stream, Q, P); break;
+            case 2: hipLaunchKernelGGL((warp_idt_kernel<2, false>), grid, block, 0, stream, Q, P); break;
+            case 3: hipLaunchKernelGGL((warp_idt_kernel<3, false>), grid, block, 0, stream, Q, P); break;
+            default: hipLaunchKernelGGL((warp_idt_kernel<4, false>), grid, block, 0, stream, Q, P); break;
+        }
     }
     DS_CHECK_LAUNCH();
     return DS_OK;

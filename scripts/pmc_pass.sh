@@ -7,7 +7,7 @@ set -u
 tag=$1; wl=$2; shift 2
 out=gpurun_out/pmc_$tag
 export TMPDIR=/tmp
-timeout -s KILL 240 rocprofv3 --pmc "$@" --kernel-trace -d "$out" -o p --output-format csv -- python3 bench.py --workload "$wl" --steps 3 --warmup 1 --no-cpu --cold-steps 0 --pipelined 0 > "$out.log" 2>&1
+timeout -s KILL 240 rocprofv3 --pmc "$@" --kernel-trace -d "$out" -o p --output-format csv -- python3 bench.py --workload "$wl" --steps 3 --warmup 1 --no-cpu --cold-steps 0 --pipelined 0 --spin-up 0 > "$out.log" 2>&1
 rc=$?
 echo "pass $tag rc=$rc"
 [ $rc -eq 0 ] || exit $rc
