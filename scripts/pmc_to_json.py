@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 # bench.py's call names -> the kernels a call launches (finalize kernels: a single wave, left out)
-KERNELS = {"warp_identity": "warp_idt_kernel<2>", "loss_fb_warp_bwd": "photo_fb_kernel<2, true>",
+KERNELS = {"warp_identity": "warp_idt_kernel<2, true>", "loss_fb_warp_bwd": "photo_fb_kernel<2, true>",
            "loss_fb": "photo_fb_kernel<2, false>", "warp_bwd": "warp_bwd_kernel<3, false>",
            "warp_fwd": "warp_fwd_kernel<3>", "loss_fwd": "photo_fwd_kernel<2, true>", "loss_bwd": "photo_bwd_kernel<2, true>",
            "metrics": "metrics_kernel"}
