@@ -574,6 +574,44 @@ def test_fused_forward_backward_kernel(de, B, S, H, W):
     assert rc == -2 or (rc == -1 and S != 3)     # three sources: unsupported (bad_dims first only if the planes overflow)
 
 
+@pytest.mark.parametrize("B,S,H,W", [(12, 2, 192, 640), (3, 1, 37, 131), (2, 2, 5, 3), (1, 2, 2, 2), (2, 2, 23, 64), (2, 2, 64, 65),
+                                     (2, 3, 40, 72), (1, 4, 33, 130), (1, 2, 3, 200), (5, 2, 96, 320)])
+def test_warp_and_identity_in_one_launch(de, B, S, H, W):
+    """ds_warp_identity_fwd: the warp and the identity loss map of train.py:85 from ONE launch -- for S <= 2 the waves of
+    the loss workgroups warp the band's rows themselves (E wave: source 0, channel waves: the last source, gathers issued
+    a step ahead), for S > 2 warp workgroups run beside loss workgroups -- against the two entry points it replaces,
+    bit for bit: warped == ds_warp_fwd, idt_loss == the identity map of ds_fused_loss_fwd.  Sizes below, at and off the
+    64-column band, the 2-row unit and the 4-row slab, one- to four-row images."""
+    L = de._lib
+    lib, st = L.lib(), L.stream()
+    g = torch.Generator().manual_seed(B * 100 + S * 10 + H + W)
+    N_ = B * S
+    src = torch.rand(B, S, 3, H, W, generator=g).to(DEV)
+    tgt = torch.rand(B, 3, H, W, generator=g).to(DEV)
+    depth = (1 + 79 * torch.rand(B, S, H, W, generator=g)).to(DEV)
+    vec = (0.02 * torch.randn(N_, 6, generator=g)).to(DEV)
+    pose = de.synthesis.construct_pose_batch(vec, DEV).reshape(B, S, 3, 4).contiguous()
+    K, Kinv = [t.to(DEV) for t in de.fused.intrinsics(W, H)]
+    warped1 = torch.full((B, S, 3, H, W), float("nan"), device=DEV)
+    idt1 = torch.full((B, H, W), float("nan"), device=DEV)
+    L.check(lib.ds_warp_identity_fwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
+                                     tgt.data_ptr(), B, S, H, W, warped1.data_ptr(), idt1.data_ptr(), st), "ds_warp_identity_fwd")
+    warped0 = torch.empty_like(warped1)
+    L.check(lib.ds_warp_fwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(), N_, 3, H, W, H, W,
+                            warped0.data_ptr(), st), "ds_warp_fwd")
+    out0 = torch.empty(B, H, W, device=DEV)
+    idt0 = torch.empty(B, H, W, device=DEV)
+    aux0 = torch.empty(B, H, W, dtype=torch.uint8, device=DEV)
+    sums0 = torch.empty(B, 2, device=DEV)
+    n = lib.ds_fused_loss_workspace_bytes(B, H, W)
+    ws = torch.empty(max(n, 4), dtype=torch.uint8, device=DEV)
+    L.check(lib.ds_fused_loss_fwd(warped0.data_ptr(), src.data_ptr(), tgt.data_ptr(), B, S, H, W, out0.data_ptr(), idt0.data_ptr(),
+                                  aux0.data_ptr(), sums0.data_ptr(), ws.data_ptr(), n, st), "ds_fused_loss_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(warped1, warped0)
+    assert torch.equal(idt1, idt0)
+
+
 def test_one_call_step_with_image_gradient(de):
     """ds_loss_step_fwdbwd with g_src: the gradient w.r.t. the source images through the warp (cleared inside the call)
     equals autograd through fused_reprojection_loss(image_grad=True) -- the same scattering kernel on the same
