@@ -316,6 +316,9 @@ def main():
                          "stream, never joined between steps (0 = skip); never the headline")
     ap.add_argument("--spin-up", type=float, default=SPIN_UP_S,
                     help="seconds of untimed steps before the warm-up (device out of its idle power state); 0 for profiler passes")
+    ap.add_argument("--levels-one-stream", action="store_true",
+                    help="pyramid workloads: all levels one after the other on the main stream (default: coarse levels forked "
+                         "onto side streams and joined inside every step)")
     ap.add_argument("--dry", action="store_true", help="launcher / rendezvous check on the CPU (gloo), no kernels")
     args = ap.parse_args()
 
@@ -353,9 +356,30 @@ def main():
     torch.cuda.set_stream(main_stream)
     st = torch.cuda.current_stream().cuda_stream
 
-    def step():
+    # A pyramid's levels are independent problems, and the coarse ones cannot fill the chip (24x80 x 12 targets: 26 us for
+    # three launches that are all latency).  Inside every step the levels below the finest are forked onto side streams and
+    # joined again before the step ends: the next step still starts only after everything of this one has finished.
+    fork_levels = len(scales) > 1 and not args.levels_one_stream
+    if fork_levels:
+        side = [torch.cuda.Stream(device=dev) for _ in scales[1:]]
+        ev_start = torch.cuda.Event()
+        ev_done = [torch.cuda.Event() for _ in side]
+
+    def step_one_stream():
         for sc in scales:
             sc.step(st)
+
+    def step_forked():
+        ev_start.record(main_stream)
+        for sc, s_, e_ in zip(scales[1:], side, ev_done):
+            s_.wait_event(ev_start)
+            sc.step(s_.cuda_stream)
+            e_.record(s_)
+        scales[0].step(st)
+        for e_ in ev_done:
+            main_stream.wait_event(e_)
+
+    step = step_forked if fork_levels else step_one_stream
 
     def barrier():
         torch.cuda.synchronize()
@@ -386,6 +410,18 @@ def main():
 
     warped_px_rank = sum(sc.N * sc.H * sc.W for sc in scales)
     value = world * warped_px_rank * args.steps / elapsed / 1e9
+    levels_one_stream = None
+    if fork_levels and rank == 0:   # the same steps with every level on the main stream, for comparison
+        for _ in range(args.warmup):
+            step_one_stream()
+        torch.cuda.synchronize()
+        l0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_one_stream()
+        torch.cuda.synchronize()
+        ldt = time.perf_counter() - l0
+        levels_one_stream = {"value": round(warped_px_rank * args.steps / ldt / 1e9, 4), "unit": "Gpix/s (this rank)",
+                             "ms_per_step": round(ldt / args.steps * 1e3, 5)}
     step_bytes = sum(sc.step_bytes for sc in scales)
     kernel_sum_bytes = sum(sum(sc.alg_bytes.values()) for sc in scales)
 
@@ -483,8 +519,11 @@ def main():
             "config": {"workload": args.workload, "targets_per_gpu": wl["B"], "sources_per_target": wl["S"],
                        "height": wl["H"], "width": wl["W"], "scales": wl["scales"], "image_grad": bool(image_grad),
                        "metrics_reduce": bool(wl.get("metrics", False)),
-                       "launch": "eager, whole batch on one stream, steps ordered (joined); " +
-                                 ("one C-ABI call per pyramid level (ds_loss_step_fwdbwd)" if wl["scales"] > 1 else "one C-ABI call per step (ds_loss_step_fwdbwd)"),
+                       "launch": "eager, steps ordered (every step starts after the previous one has finished); " +
+                                 (("one C-ABI call per pyramid level (ds_loss_step_fwdbwd); " +
+                                   ("finest level on the main stream, the others forked onto side streams and joined inside every step"
+                                    if fork_levels else "all levels on one stream"))
+                                  if wl["scales"] > 1 else "whole batch on one stream, one C-ABI call per step (ds_loss_step_fwdbwd)"),
                        "parallelism": f"batch-sharded x{world}, no collective", "spin_up_s": args.spin_up},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(hbm_frac, 4), "traffic": traffic,
@@ -500,6 +539,8 @@ def main():
             # warped and g_warped round trips between them)
             "kernel_sum_alg_GBps": round(kernel_sum_bytes / (ms * 1e-3) / 1e9, 1),
         }
+        if levels_one_stream is not None:
+            line["levels_on_one_stream"] = levels_one_stream
         if pipelined is not None:
             line["pipelined_unjoined"] = pipelined
         if cold is not None:

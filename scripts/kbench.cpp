@@ -172,6 +172,18 @@ int main(int argc, char** argv) {
                 if (rc) { fprintf(stderr, "ds_loss_step_fwdbwd rc=%d\n", rc); exit(1); }
             });
             printf("   ds_loss_step_fwdbwd (one call, merged finalize): %.4f ms per step = %.2f Gpix/s\n", one, (double)N * HW / one / 1e6);
+            // the same call captured into a HIP graph (one graph launch per step; 10 steps per graph as a second variant)
+            for (int per : {1, 10}) {
+                hipGraph_t gr; hipGraphExec_t ge;
+                CK(hipStreamBeginCapture(s1, hipStreamCaptureModeGlobal));
+                for (int k = 0; k < per; ++k)
+                    stepf(K, Kinv, pose, depth, src, tgt, nullptr, B, S, H, W, warped, out, idt, aux, sums, g_warped, g_depth, g_pose, g_src, w3, n3, s1);
+                CK(hipStreamEndCapture(s1, &gr));
+                CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+                double gt = wall([&] { CK(hipGraphLaunch(ge, s1)); }) / per;
+                printf("   ds_loss_step_fwdbwd replayed from a HIP graph (%d steps per graph): %.4f ms per step\n", per, gt);
+                CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(gr));
+            }
         }
         typedef int (*fb_t)(const float*, const float*, const float*, const float*, int, int, int, int, float*, uint8_t*, float*, float*, void*, size_t, void*);
         if (auto fb = (fb_t)dlsym(h, "ds_fused_loss_fb")) {
