@@ -17,7 +17,8 @@
 // changing the rounding order.
 #ifndef DS_EXP
 #define DS_EXP 0   // experiments (scripts/build_exp.sh), forward kernel, bit mask: 1 = synthetic row values instead of
-                   // global loads, 2 = no workgroup barriers (wrong results; timing only)
+                   // global loads, 2 = no workgroup barriers, 8 = the loss workgroups of warp_idt_kernel do not warp (wrong
+                   // results; timing only)
 #endif
 #include "ds_common.h"
 #include "ds_warp_dev.h"
@@ -1815,9 +1816,9 @@ int ds::warp_and_identity(const float* K, const float* Kinv, const float* pose, 
     P.out = idt_loss; P.aux = nullptr;
     // S <= 2: every workgroup is a loss workgroup whose waves also warp (55 / 95 VGPRs at S = 1 / 2: eight / five per CU);
     // S > 2: warp workgroups and loss workgroups side by side in one launch
-    static const int ew_per_cu = getenv("DS_EW_PERCU") ? atoi(getenv("DS_EW_PERCU")) : 0;
+    // (the chunking is flat in the assumed residency between 4 and 8 per CU, profiles/r02_kb3_warp_identity_one_launch.txt)
     const bool ew = S <= 2;
-    const Geom gm = ew ? make_fwd_lds_geom(B, H, W, S, ew_per_cu > 0 ? ew_per_cu : (S == 1 ? 8 : 5)) : make_fwd_geom(B, H, W, S, false);
+    const Geom gm = ew ? make_fwd_lds_geom(B, H, W, S, S == 1 ? 8 : 5) : make_fwd_geom(B, H, W, S, false);
     P.nbx = gm.nbx; P.nby = gm.nby; P.RB = gm.RB;
     WarpIdtParams Q{};
     Q.K = K; Q.Kinv = Kinv; Q.pose = pose; Q.depth = depth; Q.src = src; Q.warped = warped;
