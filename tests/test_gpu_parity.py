@@ -575,7 +575,7 @@ def test_fused_forward_backward_kernel(de, B, S, H, W):
 
 
 @pytest.mark.parametrize("B,S,H,W", [(12, 2, 192, 640), (3, 1, 37, 131), (2, 2, 5, 3), (1, 2, 2, 2), (2, 2, 23, 64), (2, 2, 64, 65),
-                                     (2, 3, 40, 72), (1, 4, 33, 130), (1, 2, 3, 200), (5, 2, 96, 320)])
+                                     (2, 3, 40, 72), (1, 4, 33, 130), (1, 2, 3, 200), (5, 2, 96, 320), (1, 2, 1080, 1920)])
 def test_warp_and_identity_in_one_launch(de, B, S, H, W):
     """ds_warp_identity_fwd: the warp and the identity loss map of train.py:85 from ONE launch -- for S <= 2 the waves of
     the loss workgroups warp the band's rows themselves (E wave: source 0, channel waves: the last source, gathers issued
@@ -655,7 +655,7 @@ def test_eager_step_matches_the_two_call_step(de):
     kernels, same partial-sum layout), gradients under a non-unit upstream gradient to 1e-4 of the largest (BASELINE's
     gradient bar; the factor enters before the warp backward's cancelling sums in one form and after them in the other:
     1e-5 observed); B=12 192x640 and ragged."""
-    for B, S, H, W in ((12, 2, 192, 640), (3, 3, 37, 131), (2, 4, 26, 64), (1, 1, 2, 2)):
+    for B, S, H, W in ((12, 2, 192, 640), (3, 3, 37, 131), (2, 4, 26, 64), (1, 1, 2, 2), (1, 2, 1080, 1920), (2, 1, 375, 1242)):
         g = torch.Generator().manual_seed(B * 100 + H)
         src = torch.rand(B, S, 3, H, W, generator=g).to(DEV)
         tgt = torch.rand(B, 3, H, W, generator=g).to(DEV)
