@@ -17,6 +17,7 @@ _fp = C.c_void_p
 _i = C.c_int
 _ll = C.c_longlong
 _sz = C.c_size_t
+_f32 = C.c_float
 
 # name -> (restype, argtypes); mirrors include/depthsynth.h one to one
 _SIGNATURES = {
@@ -58,6 +59,8 @@ _SIGNATURES = {
     "ds_loss_step_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _sz, _fp]),
     "ds_loss_step_fwdbwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ds_loss_step_fwdbwd": (_i, [_fp] * 7 + [_i] * 4 + [_fp] * 9 + [_fp, _sz, _fp]),
+    "ds_train_step_fwdbwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ds_train_step_fwdbwd": (_i, [_fp] * 6 + [_f32] + [_i] * 4 + [_fp] * 10 + [_fp, _sz, _fp]),
     "ds_smooth_workspace_bytes": (_sz, [_i, _i, _i]),
     "ds_smooth_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp, _sz, _fp]),
     "ds_smooth_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp]),

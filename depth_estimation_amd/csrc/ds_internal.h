@@ -80,4 +80,23 @@ DS_HIDDEN int warp_bwd_partials(const float* K, const float* Kinv, const float* 
                                 const float* g_warped, int N, int C, int Hs, int Ws, int H, int W, float* g_depth,
                                 float* g_src, void* workspace, size_t workspace_bytes, int* nblk, hipStream_t stream);
 
+// metrics.regularization_term and its gradient in one kernel (ds_misc.hip): g_depths (B,S,H,W) += scale * d reg / d depth;
+// partials (smooth_fb_partials_count floats): per-wave sums whose total / (B*S*H*W*3) is reg.
+DS_HIDDEN size_t smooth_fb_partials_count(int B, int S, int H, int W);
+DS_HIDDEN int smooth_fb_partials(const float* depths, const float* targets, float scale, int B, int S, int H, int W,
+                                 float* g_depths, float* partials, int* n_partials, hipStream_t stream);
+
+// compute units of the current device; cached (the devices of one node are alike), 256 if the query fails
+inline int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        n = cus;
+    }
+    return n;
+}
+
 }  // namespace ds

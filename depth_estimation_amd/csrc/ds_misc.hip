@@ -5,6 +5,7 @@
 // metrics.rmse/rmsle/abs_rel/sq_rel (metrics.py:100-153).
 #include "ds_common.h"
 #include "ds_warp_dev.h"
+#include "ds_internal.h"
 #include <algorithm>
 #include <mutex>
 #include "depthsynth.h"
@@ -310,10 +311,12 @@ __global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(const float* __res
 // pixels with a 1e-4 relative bar, not a bit-exact map.  torch.gradient's one-sided edges are the same
 // difference of clamped neighbours with scale 1 instead of 1/2.
 constexpr int kSmoothRows = 8;      // forward: rows per wave
-constexpr int kSmoothBwdRows = 16;  // backward: rows per wave (two extra rows of q on top)
+constexpr int kSmoothBwdRows = 16;  // backward: rows per wave (two extra rows of q on top); 8 or 4 for launches that
+                                    // would leave the chip mostly empty (smooth_bwd_rows)
 constexpr int kSmoothMaxS = 4;      // maps of one target per pass
 
-struct SmoothGeom { int H, W, nbx, S, s0, sn; };  // S maps per target; this launch handles maps s0 .. s0+sn-1 of each
+struct SmoothGeom { int H, W, nbx, S, s0, sn, rows; };  // S maps per target; this launch handles maps s0 .. s0+sn-1 of
+                                                           // each; rows: rows per wave (backward)
 
 __device__ __forceinline__ float edge_scale(int i, int L) { return (i == 0 || i == L - 1) ? 1.0f : 0.5f; }
 __device__ __forceinline__ float neg_exp(float a) { return __builtin_amdgcn_exp2f(a * -1.4426950408889634f); }
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(kThreads) void smooth_tiled_bwd_kernel(const float*
     const int t = blockIdx.y, HW = G.H * G.W;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int bx = blockIdx.x % G.nbx, by = blockIdx.x / G.nbx;
-    const int ya = (by * (kThreads / 64) + wave) * kSmoothBwdRows, yb = min(ya + kSmoothBwdRows, G.H);
+    const int ya = (by * (kThreads / 64) + wave) * G.rows, yb = min(ya + G.rows, G.H);
     if (ya >= G.H) return;
     const int x = bx * 62 - 1 + lane, xc = min(max(x, 0), G.W - 1), xl = max(xc - 1, 0), xr = min(xc + 1, G.W - 1);
     const bool store = lane >= 1 && lane <= 62 && x < G.W;
@@ -447,13 +450,103 @@ __global__ __launch_bounds__(kThreads) void smooth_tiled_bwd_kernel(const float*
     }
 }
 
+// Forward value and gradient of a10 in one pass (the step that wants both at once, ds_train_step_fwdbwd): the backward
+// kernel above with the gradient's upstream factor g = scale / count from the host, accumulating into g_depths, plus the
+// forward's sum over the pixels a wave stores (one partial per wave, fixed order in the finalize).
+template <int S>
+__global__ __launch_bounds__(kThreads) void smooth_tiled_fb_kernel(const float* __restrict__ depths,
+                                                                    const float* __restrict__ targets,
+                                                                   float g, SmoothGeom G, float* __restrict__ g_depths,
+                                                                   float* __restrict__ partials) {
+    const int t = blockIdx.y, HW = G.H * G.W;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int bx = blockIdx.x % G.nbx, by = blockIdx.x / G.nbx;
+    const int ya = (by * (kThreads / 64) + wave) * G.rows, yb = min(ya + G.rows, G.H);
+    float* part = partials + ((size_t)t * gridDim.x + blockIdx.x) * (kThreads / 64) + wave;
+    if (ya >= G.H) {
+        if (lane == 0) *part = 0.f;
+        return;
+    }
+    float acc = 0.f;   // this wave's part of sum |dD| * w (the forward value; rows ya .. yb-1, columns it stores)
+    const int x = bx * 62 - 1 + lane, xc = min(max(x, 0), G.W - 1), xl = max(xc - 1, 0), xr = min(xc + 1, G.W - 1);
+    const bool store = lane >= 1 && lane <= 62 && x < G.W;
+    const float sx = edge_scale(xc, G.W);
+    const float* I = targets + (size_t)t * 3 * HW;
+    const float* D = depths + ((size_t)t * G.S + G.s0) * HW;
+    float* O = g_depths + ((size_t)t * G.S + G.s0) * HW;
+    auto row_of = [&](int r) { return min(max(r, 0), G.H - 1) * G.W; };
+    float ic[3][3], dc[S][3], qy[S][2], gx[S];  // qy[.][0], [1] = q_y of rows r-2, r-1; gx = x part of output row r-1
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        ic[c][1] = I[c * HW + row_of(ya - 2) + xc];
+        ic[c][2] = I[c * HW + row_of(ya - 1) + xc];
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        dc[s][1] = D[s * HW + row_of(ya - 2) + xc];
+        dc[s][2] = D[s * HW + row_of(ya - 1) + xc];
+        qy[s][0] = qy[s][1] = 0.f;
+        gx[s] = 0.f;
+    }
+    for (int r = ya - 1; r <= yb; ++r) {
+        const bool live = r >= 0 && r < G.H;  // wave-uniform
+        const int rn = row_of(r + 1), ro = row_of(r);
+        const float sy = edge_scale(r, G.H);
+        float wx = 0.f, wy = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ic[c][0] = ic[c][1];
+            ic[c][1] = ic[c][2];
+            ic[c][2] = I[c * HW + rn + xc];
+            wx += neg_exp(fabsf(I[c * HW + ro + xr] - I[c * HW + ro + xl]) * sx);
+            wy += neg_exp(fabsf(ic[c][2] - ic[c][0]) * sy);
+        }
+        const int y = r - 1;  // the output row of this iteration
+        const bool emit = y >= ya && y < yb;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            dc[s][0] = dc[s][1];
+            dc[s][1] = dc[s][2];
+            dc[s][2] = D[s * HW + rn + xc];
+            const float ddx = D[s * HW + ro + xr] - D[s * HW + ro + xl], ddy = dc[s][2] - dc[s][0];
+            float qx = g * wx * sgn(ddx) * sx;
+            float qyn = g * wy * sgn(ddy) * sy;
+            if (!live) qx = qyn = 0.f;
+            if (store && r >= ya && r < yb) acc += fmaf(fabsf(ddx) * sx, wx, (fabsf(ddy) * sy) * wy);
+            const float ql = __shfl_up(qx, 1, 64), qr = __shfl_down(qx, 1, 64);
+            const float gxn = (xc >= 1 ? ql : -qx) - (xc <= G.W - 2 ? qr : -qx);
+            if (emit && store) {
+                const float up = y >= 1 ? qy[s][0] : -qy[s][1];
+                const float down = y <= G.H - 2 ? qyn : -qy[s][1];
+                float* o = O + s * HW + y * G.W + x;
+                const float v = gx[s] + (up - down);
+                *o += v;
+            }
+            qy[s][0] = qy[s][1];
+            qy[s][1] = qyn;
+            gx[s] = gxn;
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) *part = acc;
+}
+
 inline int smooth_fwd_blocks(int H, int W) {
     const int per = (kThreads / 64) * kSmoothRows;
     return ((W + 63) / 64) * ((H + per - 1) / per);
 }
-inline int smooth_bwd_blocks(int H, int W) {
-    const int per = (kThreads / 64) * kSmoothBwdRows;
+inline int smooth_bwd_blocks(int H, int W, int rows) {
+    const int per = (kThreads / 64) * rows;
     return ((W + 61) / 62) * ((H + per - 1) / per);
+}
+// A wave walks its rows one after the other, every step waiting for its loads: with 16 rows per wave 12 targets of
+// 192x640 are 396 workgroups -- 27 us of latency on a mostly empty chip (the forward + backward of the whole photometric
+// loss take 100).  Shorter walks until the launch has about eight workgroups per CU; the outputs do not depend on it.
+inline int smooth_bwd_rows(int B, int H, int W) {
+    const long long want = 8ll * ds::cu_count();
+    int rows = kSmoothBwdRows;
+    while (rows > 4 && (long long)B * smooth_bwd_blocks(H, W, rows) < want) rows >>= 1;
+    return rows;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -981,7 +1074,7 @@ int ds_smooth_batch_fwd(const float* depths, const float* targets, int B, int S,
     const int nblk = smooth_fwd_blocks(H, W), per_pass = B * nblk * (kThreads / 64);
     int passes = 0;
     for (int s0 = 0; s0 < S; s0 += kSmoothMaxS, ++passes) {
-        const SmoothGeom G{H, W, (W + 63) / 64, S, s0, std::min(kSmoothMaxS, S - s0)};
+        const SmoothGeom G{H, W, (W + 63) / 64, S, s0, std::min(kSmoothMaxS, S - s0), kSmoothRows};
         float* out = partials + (size_t)passes * per_pass;
         dim3 grid(nblk, B), blk(kThreads);
         switch (G.sn) {
@@ -1012,9 +1105,10 @@ int ds_smooth_batch_bwd(const float* depths, const float* targets, const float* 
         return DS_OK;
     }
     const float inv_count = (float)(1.0 / ((double)N * H * W * 3.0));
+    const int rows = smooth_bwd_rows(B, H, W);
     for (int s0 = 0; s0 < S; s0 += kSmoothMaxS) {
-        const SmoothGeom G{H, W, (W + 61) / 62, S, s0, std::min(kSmoothMaxS, S - s0)};
-        dim3 grid(smooth_bwd_blocks(H, W), B), blk(kThreads);
+        const SmoothGeom G{H, W, (W + 61) / 62, S, s0, std::min(kSmoothMaxS, S - s0), rows};
+        dim3 grid(smooth_bwd_blocks(H, W, rows), B), blk(kThreads);
         switch (G.sn) {
             case 1: hipLaunchKernelGGL(smooth_tiled_bwd_kernel<1>, grid, blk, 0, st, depths, targets, g_value, inv_count, G, accumulate, g_depths); break;
             case 2: hipLaunchKernelGGL(smooth_tiled_bwd_kernel<2>, grid, blk, 0, st, depths, targets, g_value, inv_count, G, accumulate, g_depths); break;
@@ -1025,6 +1119,39 @@ int ds_smooth_batch_bwd(const float* depths, const float* targets, const float* 
     }
     return DS_OK;
 }
+
+}  // extern "C"
+
+size_t ds::smooth_fb_partials_count(int B, int S, int H, int W) {
+    if (B <= 0 || S <= 0 || H < 2 || W < 2) return 0;
+    const int passes = (S + kSmoothMaxS - 1) / kSmoothMaxS;
+    return (size_t)passes * B * smooth_bwd_blocks(H, W, 4) * (kThreads / 64);   // the shortest walk has the most waves
+}
+
+int ds::smooth_fb_partials(const float* depths, const float* targets, float scale, int B, int S, int H, int W, float* g_depths,
+                           float* partials, int* n_partials, hipStream_t st) {
+    if (!depths || !targets || !g_depths || !partials || B <= 0 || S <= 0 || (long long)B * S > 65535 || bad_img(B * S, 3, H, W))
+        return DS_ERR_INVALID_ARG;
+    const float g = scale * (float)(1.0 / ((double)B * S * H * W * 3.0));
+    const int rows = smooth_bwd_rows(B, H, W), nblk = smooth_bwd_blocks(H, W, rows), per_pass = B * nblk * (kThreads / 64);
+    int passes = 0;
+    for (int s0 = 0; s0 < S; s0 += kSmoothMaxS, ++passes) {
+        const SmoothGeom G{H, W, (W + 61) / 62, S, s0, std::min(kSmoothMaxS, S - s0), rows};
+        float* out = partials + (size_t)passes * per_pass;
+        dim3 grid(nblk, B), blk(kThreads);
+        switch (G.sn) {
+            case 1: hipLaunchKernelGGL(smooth_tiled_fb_kernel<1>, grid, blk, 0, st, depths, targets, g, G, g_depths, out); break;
+            case 2: hipLaunchKernelGGL(smooth_tiled_fb_kernel<2>, grid, blk, 0, st, depths, targets, g, G, g_depths, out); break;
+            case 3: hipLaunchKernelGGL(smooth_tiled_fb_kernel<3>, grid, blk, 0, st, depths, targets, g, G, g_depths, out); break;
+            default: hipLaunchKernelGGL(smooth_tiled_fb_kernel<4>, grid, blk, 0, st, depths, targets, g, G, g_depths, out); break;
+        }
+        DS_CHECK_LAUNCH();
+    }
+    *n_partials = passes * per_pass;
+    return DS_OK;
+}
+
+extern "C" {
 
 int ds_smooth_fwd(const float* depths, const float* targets, int N, int C, int H, int W, float* value, void* workspace,
                   size_t workspace_bytes, void* stream) {

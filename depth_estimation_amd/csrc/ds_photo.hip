@@ -1495,17 +1495,7 @@ __global__ __launch_bounds__(64 * kWaves) void ssim_bwd_kernel(const float* __re
 // ---------------------------------------------------------------------------------------------------
 struct Geom { int nbx, nby, RB, nblocks, nwaves; };
 
-inline int simd_count() {  // SIMDs of the current device (4 per CU); cached, devices of one node are alike
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        n = 4 * cus;
-    }
-    return n;
-}
+inline int simd_count() { return 4 * ds::cu_count(); }  // SIMDs of the current device (4 per CU)
 
 // Rows per wave.  The kernels are VALU-bound, so a launch takes about (waves on the busiest SIMD) x (rows a wave
 // walks, halo rows included); a SIMD needs two resident waves to issue back to back.  Pick the row chunk that

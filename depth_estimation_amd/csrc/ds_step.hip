@@ -1,7 +1,9 @@
-// ds_step.hip -- the two halves of a loss step (train.py:72-88 for B targets and its autograd) as one call each.
+// ds_step.hip -- a loss step (train.py:72-88 for B targets and its autograd) as two calls, as one call, and with the
+// smoothness term of train.py:89 as one call.
 //
-// Host code only: no kernels here.  A caller that goes through a slow foreign-function layer (ctypes, cgo, JNI) pays for
-// every call; these two entry points issue the same launches as the four calls they replace, on the caller's stream.
+// Host code and the small finalize kernels of the one-call forms.  A caller that goes through a slow foreign-function
+// layer (ctypes, cgo, JNI) pays for every call; these entry points issue the launches of the calls they replace, on the
+// caller's stream.
 //
 // Measured and dropped: cutting the batch into parts on side streams inside each call (fork and join by events).  The
 // memory-bound warp kernels of one part do overlap the VALU-bound loss kernels of another, but a join after every half
@@ -25,6 +27,31 @@ __global__ __launch_bounds__(64) void step_finalize_kernel(const float* __restri
     const int i = blockIdx.x;
     if (i < B) ds::loss_finalize_wave(loss_partials, i, waves_per_image, inv_hw, sums, threadIdx.x);
     else ds::pose_finalize_wave(pose_partials, i - B, nblk, g_pose, threadIdx.x);
+}
+
+// The end of ds_train_step_fwdbwd: reg = sum of the smoothness kernel's per-wave partials / count (fixed order, double),
+// total = sum_b sums[b][0] + scale * reg (train.py:88-89).  One workgroup.
+constexpr int kTrainFinThreads = 1024;
+__global__ __launch_bounds__(kTrainFinThreads) void train_finalize_kernel(const float* __restrict__ partials, int n,
+                                                                          double inv_count, float scale,
+                                                                          const float* __restrict__ sums, int B,
+                                                                          float* __restrict__ reg, float* __restrict__ total) {
+    __shared__ double lds[kTrainFinThreads / 64];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += kTrainFinThreads) a += (double)partials[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kTrainFinThreads / 64; ++w) t += lds[w];
+        const float r = (float)(t * inv_count);
+        float loss = 0.f;
+        for (int b = 0; b < B; ++b) loss += sums[2 * b];
+        reg[0] = r;
+        total[0] = loss + scale * r;
+    }
 }
 
 inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
@@ -162,6 +189,36 @@ int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, co
     if (rc != DS_OK) return rc;
     hipLaunchKernelGGL(step_finalize_kernel, dim3(B + B * S), dim3(64), 0, st, (const float*)ws_loss, wpi,
                        1.0 / ((double)H * W), sums, B, (const float*)ws_warp, nblk, g_pose);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+size_t ds_train_step_fwdbwd_workspace_bytes(int B, int S, int H, int W) {
+    const size_t a = ds_loss_step_fwdbwd_workspace_bytes(B, S, H, W);
+    if (a == 0) return 0;
+    return align256(a) + ds::smooth_fb_partials_count(B, S, H, W) * sizeof(float);
+}
+
+int ds_train_step_fwdbwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                         const float* target, float smooth_scale, int B, int S, int H, int W, float* warped,
+                         float* out_loss, float* idt_loss, uint8_t* aux, float* sums, float* reg, float* total,
+                         float* g_warped, float* g_depth, float* g_pose, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+    if (!reg || !total) return DS_ERR_INVALID_ARG;
+    if (B <= 0 || S <= 0 || H < 2 || W < 2) return DS_ERR_INVALID_ARG;
+    if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ds_train_step_fwdbwd_workspace_bytes(B, S, H, W))
+        return DS_ERR_WORKSPACE;
+    const size_t n_step = align256(ds_loss_step_fwdbwd_workspace_bytes(B, S, H, W));
+    int rc = ds_loss_step_fwdbwd(K, Kinv, pose, depth, src, target, nullptr, B, S, H, W, warped, out_loss, idt_loss, aux, sums,
+                                 g_warped, g_depth, g_pose, nullptr, workspace, n_step, stream);
+    if (rc != DS_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    float* partials = (float*)((char*)workspace + n_step);
+    int n = 0;
+    rc = ds::smooth_fb_partials(depth, target, smooth_scale, B, S, H, W, g_depth, partials, &n, st);
+    if (rc != DS_OK) return rc;
+    hipLaunchKernelGGL(train_finalize_kernel, dim3(1), dim3(kTrainFinThreads), 0, st, (const float*)partials, n,
+                       1.0 / ((double)B * S * H * W * 3.0), smooth_scale, (const float*)sums, B, reg, total);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

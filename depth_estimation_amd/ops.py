@@ -409,9 +409,9 @@ class _TrainStep(torch.autograd.Function):
 
 
 class _TrainStepEager(torch.autograd.Function):
-    """The same step with its gradients formed in the forward call: ds_loss_step_fwdbwd (forward and backward launches
-    back to back, one merged finalize) + the smoothness pair.  total is linear in its upstream gradient, so backward only
-    scales the stored gradients by it (loss.backward() passes 1)."""
+    """The same step with its gradients formed in the forward call: ONE C call, ds_train_step_fwdbwd (the photometric step's
+    three launches, the smoothness value and gradient from one kernel, a finalize that also forms total).  total is linear
+    in its upstream gradient, so backward only scales the stored gradients by it (loss.backward() passes 1)."""
 
     @staticmethod
     def forward(ctx, K, Kinv, pose, depth, src, target, smooth_scale):
@@ -427,23 +427,18 @@ class _TrainStepEager(torch.autograd.Function):
         L.same_device(depth, src, target, K, Kinv, pose)
         dev, lib, st = src.device, L.lib(), L.stream()
         f32 = dict(dtype=torch.float32, device=dev)
-        nb = max(lib.ds_loss_step_fwdbwd_workspace_bytes(b, s, h, w), lib.ds_smooth_workspace_bytes(n, h, w))
+        nb = lib.ds_train_step_fwdbwd_workspace_bytes(b, s, h, w)
         wsb = L.workspace.get(nb, dev)
         warped, gw = torch.empty(b, s, 3, h, w, **f32), torch.empty(b, s, 3, h, w, **f32)
         out, idt = torch.empty(b, h, w, **f32), torch.empty(b, h, w, **f32)
         aux = torch.empty(b, h, w, dtype=torch.uint8, device=dev)
-        sums, reg = torch.empty(b, 2, **f32), torch.empty(1, **f32)
+        sums, reg, total = torch.empty(b, 2, **f32), torch.empty(1, **f32), torch.empty((), **f32)
         gd, gp = torch.empty_like(depth), torch.empty(n, 3, 4, **f32)
-        L.check(lib.ds_loss_step_fwdbwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
-                                        target.data_ptr(), 0, b, s, h, w, warped.data_ptr(), out.data_ptr(), idt.data_ptr(),
-                                        aux.data_ptr(), sums.data_ptr(), gw.data_ptr(), gd.data_ptr(), gp.data_ptr(), 0,
-                                        wsb.data_ptr(), nb, st), "ds_loss_step_fwdbwd")
-        L.check(lib.ds_smooth_batch_fwd(depth.data_ptr(), target.data_ptr(), b, s, 3, h, w, reg.data_ptr(), wsb.data_ptr(), nb,
-                                        st), "ds_smooth_batch_fwd")
-        g_reg = torch.full((1,), smooth_scale, **f32)
-        L.check(lib.ds_smooth_batch_bwd(depth.data_ptr(), target.data_ptr(), g_reg.data_ptr(), b, s, 3, h, w, 1,
-                                        gd.data_ptr(), st), "ds_smooth_batch_bwd")
-        total = sums[:, 0].sum() + smooth_scale * reg[0]
+        L.check(lib.ds_train_step_fwdbwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
+                                         target.data_ptr(), smooth_scale, b, s, h, w, warped.data_ptr(), out.data_ptr(),
+                                         idt.data_ptr(), aux.data_ptr(), sums.data_ptr(), reg.data_ptr(), total.data_ptr(),
+                                         gw.data_ptr(), gd.data_ptr(), gp.data_ptr(), wsb.data_ptr(), nb, st),
+                "ds_train_step_fwdbwd")
         ctx.save_for_backward(gd, gp)
         ctx.mark_non_differentiable(sums, reg, warped, out, idt, aux)
         ctx.set_materialize_grads(False)

@@ -179,7 +179,8 @@ int ds_loss_step_bwd(const float* K, const float* Kinv, const float* pose, const
 
 /* The whole loss step -- train.py:72-88 for B targets AND its autograd -- in one call: forward and backward launches
  * back to back on the caller's stream, the two fixed-order finalisations (per-target means, pose gradients) merged into
- * one launch at the end (five dependent launches instead of six).  The loss of train.py:88 is linear in every
+ * one launch at the end (S <= 2 without g_src: three launches -- warp + identity loss, loss forward + adjoint + the
+ * warp's autograd, finalize; otherwise five).  The loss of train.py:88 is linear in every
  * sums[b][0], so the gradients can be formed before the caller's backward runs: g_sums (B) = d(loss)/d(sums[b][0]), or
  * NULL for a unit upstream gradient -- what loss.backward() passes for the reference's summed loss (train.py:88,103); a
  * caller with another upstream factor scales g_depth and g_pose by it.  Outputs as in the four calls it replaces;
@@ -192,6 +193,19 @@ int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, co
                         const float* target, const float* g_sums, int B, int S, int H, int W, float* warped,
                         float* out_loss, float* idt_loss, uint8_t* aux, float* sums, float* g_warped, float* g_depth,
                         float* g_pose, float* g_src, void* workspace, size_t workspace_bytes, void* stream);
+
+/* train.py:72-89 for B targets and its autograd in one call: ds_loss_step_fwdbwd (unit upstream gradient, no image
+ * gradient) plus the smoothness term of train.py:89 on the S depth maps of every target against that target
+ * (metrics.regularization_term, metrics.py:75-97) with its gradient accumulated onto g_depth -- forward value and
+ * gradient from one kernel -- and a last launch that forms reg (1) = regularization_term and total (1) = sum_b sums[b][0]
+ * + smooth_scale * reg.  g_depth, g_pose = d total / d depth, d total / d pose; a caller with another upstream factor
+ * scales them.  Everything else as ds_loss_step_fwdbwd; workspace from ds_train_step_fwdbwd_workspace_bytes. */
+size_t ds_train_step_fwdbwd_workspace_bytes(int B, int S, int H, int W);
+int ds_train_step_fwdbwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
+                         const float* target, float smooth_scale, int B, int S, int H, int W, float* warped,
+                         float* out_loss, float* idt_loss, uint8_t* aux, float* sums, float* reg, float* total,
+                         float* g_warped, float* g_depth, float* g_pose, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* metrics.regularization_term (metrics.py:75-97): depths (N,1,H,W), targets (N,C,H,W) -> value (1)
  * fp32 on device; workspace from ds_smooth_workspace_bytes. */

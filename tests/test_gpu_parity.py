@@ -612,6 +612,64 @@ def test_warp_and_identity_in_one_launch(de, B, S, H, W):
     assert torch.equal(idt1, idt0)
 
 
+@pytest.mark.parametrize("B,S,H,W", [(12, 2, 192, 640), (3, 3, 37, 131), (2, 1, 9, 70), (1, 2, 2, 2), (2, 4, 26, 64), (1, 2, 375, 1242)])
+def test_train_step_in_one_call(de, oracle, B, S, H, W):
+    """ds_train_step_fwdbwd (train.py:72-89 and its autograd in one C call: ds_loss_step_fwdbwd + the smoothness value and
+    gradient from one kernel + total) against the calls it replaces: maps, sums, g_pose bit for bit (the same launches),
+    g_depth bit for bit (the smoothness gradient is the same arithmetic added to the same photometric gradient), reg to
+    1e-6 relative (another order of the partial sums) and against the oracle's regularization_term (1e-5), total ==
+    sum_b sums[b,0] + scale * reg to 1e-6."""
+    L = de._lib
+    lib, st = L.lib(), L.stream()
+    g = torch.Generator().manual_seed(B * 7 + S * 3 + H + W)
+    N_ = B * S
+    src = torch.rand(B, S, 3, H, W, generator=g).to(DEV)
+    tgt = torch.rand(B, 3, H, W, generator=g).to(DEV)
+    depth = (1 + 79 * torch.rand(B, S, H, W, generator=g)).to(DEV)
+    vec = (0.02 * torch.randn(N_, 6, generator=g)).to(DEV)
+    pose = de.synthesis.construct_pose_batch(vec, DEV).reshape(B, S, 3, 4).contiguous()
+    K, Kinv = [t.to(DEV) for t in de.fused.intrinsics(W, H)]
+    scale = 0.02
+    f = dict(dtype=torch.float32, device=DEV)
+
+    def bufs():
+        return dict(warped=torch.empty(B, S, 3, H, W, **f), out=torch.empty(B, H, W, **f), idt=torch.empty(B, H, W, **f),
+                    aux=torch.empty(B, H, W, dtype=torch.uint8, device=DEV), sums=torch.empty(B, 2, **f),
+                    gw=torch.empty(B, S, 3, H, W, **f), gd=torch.empty(B, S, H, W, **f), gp=torch.empty(N_, 3, 4, **f))
+    a, b_ = bufs(), bufs()
+    reg, total = torch.empty(1, **f), torch.empty(1, **f)
+    n = lib.ds_train_step_fwdbwd_workspace_bytes(B, S, H, W)
+    ws = torch.empty(n, dtype=torch.uint8, device=DEV)
+    L.check(lib.ds_train_step_fwdbwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
+                                     tgt.data_ptr(), scale, B, S, H, W, a["warped"].data_ptr(), a["out"].data_ptr(),
+                                     a["idt"].data_ptr(), a["aux"].data_ptr(), a["sums"].data_ptr(), reg.data_ptr(),
+                                     total.data_ptr(), a["gw"].data_ptr(), a["gd"].data_ptr(), a["gp"].data_ptr(), ws.data_ptr(),
+                                     n, st), "ds_train_step_fwdbwd")
+    # the calls it replaces
+    n2 = max(lib.ds_loss_step_fwdbwd_workspace_bytes(B, S, H, W), lib.ds_smooth_workspace_bytes(N_, H, W))
+    ws2 = torch.empty(n2, dtype=torch.uint8, device=DEV)
+    L.check(lib.ds_loss_step_fwdbwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
+                                    tgt.data_ptr(), 0, B, S, H, W, b_["warped"].data_ptr(), b_["out"].data_ptr(),
+                                    b_["idt"].data_ptr(), b_["aux"].data_ptr(), b_["sums"].data_ptr(), b_["gw"].data_ptr(),
+                                    b_["gd"].data_ptr(), b_["gp"].data_ptr(), 0, ws2.data_ptr(), n2, st), "ds_loss_step_fwdbwd")
+    reg2 = torch.empty(1, **f)
+    L.check(lib.ds_smooth_batch_fwd(depth.data_ptr(), tgt.data_ptr(), B, S, 3, H, W, reg2.data_ptr(), ws2.data_ptr(), n2, st),
+            "ds_smooth_batch_fwd")
+    g_reg = torch.full((1,), scale, **f)
+    L.check(lib.ds_smooth_batch_bwd(depth.data_ptr(), tgt.data_ptr(), g_reg.data_ptr(), B, S, 3, H, W, 1, b_["gd"].data_ptr(), st),
+            "ds_smooth_batch_bwd")
+    torch.cuda.synchronize()
+    for k in ("warped", "out", "idt", "aux", "sums", "gp", "gd"):
+        assert torch.equal(a[k], b_[k]), k
+    assert abs(float(reg) - float(reg2)) <= 1e-6 * abs(float(reg2))
+    want = float(b_["sums"][:, 0].sum()) + scale * float(reg2)
+    assert abs(float(total) - want) <= 1e-6 * abs(want)
+    # regularization_term of the reference (oracle): depth maps (N,1,H,W) against their targets stacked S times
+    tg = tgt[:, None].expand(B, S, 3, H, W).reshape(N_, 3, H, W)
+    ref = oracle.regularization_term(N(depth.reshape(N_, 1, H, W)), N(tg))
+    assert abs(float(reg) - float(ref)) <= 1e-5 * abs(float(ref))
+
+
 def test_one_call_step_with_image_gradient(de):
     """ds_loss_step_fwdbwd with g_src: the gradient w.r.t. the source images through the warp (cleared inside the call)
     equals autograd through fused_reprojection_loss(image_grad=True) -- the same scattering kernel on the same
