@@ -6,6 +6,7 @@ the stated 1e-5); 1e-5 max-abs on anything that goes through expf; 1e-4 relative
 scalar metrics.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -668,6 +669,14 @@ def test_train_step_in_one_call(de, oracle, B, S, H, W):
     tg = tgt[:, None].expand(B, S, 3, H, W).reshape(N_, 3, H, W)
     ref = oracle.regularization_term(N(depth.reshape(N_, 1, H, W)), N(tg))
     assert abs(float(reg) - float(ref)) <= 1e-5 * abs(float(ref))
+
+
+def test_fused_step_differential_fuzz(de):
+    """scripts/fuzz_step.py: 80 random (B, S, H, W) with ties between sources, static scenes, near and far depths, small and
+    large poses -- ds_train_step_fwdbwd against the unfused kernels: maps bit for bit, gradients to 1e-5 of the largest."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import fuzz_step
+    assert fuzz_step.run(80, seed=11) == 0
 
 
 def test_one_call_step_with_image_gradient(de):
