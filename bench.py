@@ -36,6 +36,8 @@ import torch  # noqa: E402
 WORKLOADS = {
     # BASELINE.json metric: "fwd+bwd reproj loss @192x640" on the config-2/3 batch
     "b12_s2_192x640_fwdbwd": dict(B=12, S=2, H=192, W=640, scales=1),
+    # config 1: "fused forward warp+loss" -- the forward half alone (ds_loss_step_fwd)
+    "b12_s2_192x640_fwd": dict(B=12, S=2, H=192, W=640, scales=1, fwd_only=True),
     # config 3: the same over a 4-scale pyramid (each scale an independent call, K rows scaled per scale)
     # (the backward also scatters the source-image gradient)
     "b12_s2_192x640_pyramid4_fwdbwd": dict(B=12, S=2, H=192, W=640, scales=4, image_grad=True),
@@ -59,7 +61,7 @@ def step_alg_bytes_per_target_px(S, C=3, image_grad=False):
 class Scale:
     """All device buffers of one (B,S,H,W) problem + the C-ABI calls of a step."""
 
-    def __init__(self, de, B, S, H, W, dev, seed, image_grad, metrics=False):
+    def __init__(self, de, B, S, H, W, dev, seed, image_grad, metrics=False, fwd_only=False):
         from depth_estimation_amd import _lib as L
         self.L, self.lib = L, L.lib()
         self.B, self.S, self.H, self.W, self.N = B, S, H, W, B * S
@@ -157,6 +159,14 @@ class Scale:
                 "loss_bwd": px * (12 + 12) + tp * (12 + 4 + 1),       # warped + target + idt + aux -> g_warped
                 "warp_bwd": px * (4 + 12 + 12 + 4 + (12 if image_grad else 0)),  # depth + src + g_warped -> g_depth [+ g_src]
             }
+        if fwd_only:
+            self.ws_fwd_n = self.lib.ds_loss_step_workspace_bytes(B, S, H, W)
+            self.ws_fwd = torch.empty(max(self.ws_fwd_n, 16), dtype=torch.uint8, device=dev)
+            self.calls = {"loss_step_fwd": lambda st: lib.ds_loss_step_fwd(
+                p(self.K), p(self.Kinv), p(self.pose), p(self.depth), p(self.src), p(self.tgt), B, S, H, W, p(self.warped),
+                p(self.out), p(self.idt), p(self.aux), p(self.sums), p(self.ws_fwd), self.ws_fwd_n, st)}
+            # SURVEY 8d forward: depth + src (gather) -> warped, warped + src + target -> out, idt, aux
+            self.alg_bytes = {"loss_step_fwd": tp * 4 * (S + 2 * 3 * S + 3 + 2)}
         self.names = tuple(self.calls) + (("metrics",) if metrics else ())
         # the step as ONE call (forward + backward launches and a single merged finalize; with the image gradient also the
         # clearing of g_src)
@@ -172,6 +182,9 @@ class Scale:
             self.alg_bytes["metrics"] = tp * 8                    # pred + gt
         # what BASELINE.md prices the step with: SURVEY 8d's bytes of the fused path (no warped / g_warped round trips)
         self.step_bytes = tp * step_alg_bytes_per_target_px(S, 3, image_grad) + (tp * 8 if metrics else 0)
+        if fwd_only:
+            self.one_call = self.calls["loss_step_fwd"]
+            self.step_bytes = self.alg_bytes["loss_step_fwd"]
 
     def step(self, st, separate=False):
         if self.one_call is not None and not separate:
@@ -202,7 +215,7 @@ def build_problem(de, wl, dev, rank, image_grad, parts=1):
             b = wl["B"] // lvl_parts + (1 if j < wl["B"] % lvl_parts else 0)
             if b > 0:
                 scales.append(Scale(de, b, wl["S"], wl["H"] >> i, wl["W"] >> i, dev, 1000 * rank + 10 * i + j, image_grad,
-                                    wl.get("metrics", False)))
+                                    wl.get("metrics", False), wl.get("fwd_only", False)))
     return scales
 
 
@@ -523,7 +536,8 @@ def main():
                                  (("one C-ABI call per pyramid level (ds_loss_step_fwdbwd); " +
                                    ("finest level on the main stream, the others forked onto side streams and joined inside every step"
                                     if fork_levels else "all levels on one stream"))
-                                  if wl["scales"] > 1 else "whole batch on one stream, one C-ABI call per step (ds_loss_step_fwdbwd)"),
+                                  if wl["scales"] > 1 else "whole batch on one stream, one C-ABI call per step (" +
+                                  ("ds_loss_step_fwd: forward only" if wl.get("fwd_only") else "ds_loss_step_fwdbwd") + ")"),
                        "parallelism": f"batch-sharded x{world}, no collective", "spin_up_s": args.spin_up},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(hbm_frac, 4), "traffic": traffic,

@@ -57,6 +57,10 @@ DS_HIDDEN int fused_loss_fwd_partials(const float* warped, const float* src, con
                                       float* out_loss, float* idt_loss, uint8_t* aux, void* workspace,
                                       size_t workspace_bytes, int* waves_per_image, hipStream_t stream);
 // ds_warp_fwd (C = 3, source size = grid size) and the identity loss map ds_reprojection_loss_fwd(src, target) in ONE launch
+// the forward loss of the warped groups with the identity map given (photo_fwd_idm_kernel); partials as fused_loss_fwd_partials
+DS_HIDDEN int fused_loss_fwd_idm_partials(const float* warped, const float* target, const float* idt_loss, int B, int S, int H,
+                                          int W, float* out_loss, uint8_t* aux, void* workspace, size_t workspace_bytes,
+                                          int* waves_per_image, hipStream_t stream);
 DS_HIDDEN int warp_and_identity(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
                                 const float* target, int B, int S, int H, int W, float* warped, float* idt_loss,
                                 hipStream_t stream);

@@ -123,7 +123,8 @@ constexpr int kFwdWaves = 4;
 // EW: the E wave -- idle nine tenths of the time -- also runs ds_warp_fwd for the band's rows (Q: the warp's arguments),
 // software-pipelined around the slab barriers so that no gather is waited for: a unit = 2 rows x S sources is projected
 // and its 6 gathers per (row, source) issued, the previous unit is blended and stored while they fly.
-template <int S, bool IDT, bool EW = false>
+// IDM: the identity map is given (P.idt, read): the E wave forms the ratio and the sums from it as with IDT.
+template <int S, bool IDT, bool EW = false, bool IDM = false>
 __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid, int nblk, const WarpIdtParams* Q = nullptr) {
     constexpr int G = IDT ? 2 * S : S;
     constexpr int NP = 1 + G;
@@ -214,6 +215,10 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
         }
         int u = 0;
         for (int k0 = 0; k0 < nrows; k0 += kK) {
+            float idv[kK];   // IDM: the slab's identity values, requested before the wait
+#pragma unroll
+            for (int k = 0; k < kK; ++k)
+                idv[k] = IDM ? P.idt[(size_t)b * HW + (size_t)min(y0 + k0 + k, H - 1) * W + min(col, W - 1)] : 0.f;
 #if !(DS_EXP & 2)
             __syncthreads();  // the channel waves have filled slab (k0 / kK) & 1
 #endif
@@ -226,7 +231,9 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
             }
             const int buf = (k0 / kK) & 1;
             const int kn = min(kK, nrows - k0);
-            for (int k = 0; k < kn; ++k) {
+#pragma unroll
+            for (int k = 0; k < kK; ++k) {
+                if (k >= kn) break;   // uniform
                 float E[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g)
@@ -254,6 +261,10 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
                         sum_ratio += best / expf(bid + 1e-6f);  // train.py:88
                         sum_out += best;                        // train.py:92
                     }
+                    if (IDM) {
+                        sum_ratio += best / expf(idv[k] + 1e-6f);
+                        sum_out += best;
+                    }
                 }
             }
             if (EWX) {
@@ -265,7 +276,7 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
                 u += 2;
             }
         }
-        if (IDT) {
+        if (IDT || IDM) {
             sum_ratio = wave_sum(sum_ratio);
             sum_out = wave_sum(sum_out);
             if (lane == 0) {
@@ -448,6 +459,12 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
 template <int S, bool IDT>
 __global__ __launch_bounds__(64 * kFwdWaves, (IDT ? 2 * S : S) > 4 ? 3 : 4) void photo_fwd_kernel(PhotoFwdParams P) {
     photo_fwd_body<S, IDT>(P, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// the warped groups only, identity map given (ds_loss_step_fwd after warp_idt_kernel)
+template <int S>
+__global__ __launch_bounds__(64 * kFwdWaves, 4) void photo_fwd_idm_kernel(PhotoFwdParams P) {
+    photo_fwd_body<S, false, false, true>(P, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -1738,6 +1755,8 @@ size_t ds_fused_loss_workspace_bytes(int B, int H, int W) {
         const Geom g = make_fwd_geom(B, H, W, S, true);
         const size_t k = fwd_uses_lds(S, true) ? (size_t)g.nwaves : (size_t)g.nblocks * kWaves;
         if (k > n) n = k;
+        const size_t k2 = (size_t)make_fwd_geom(B, H, W, S, false).nwaves;   // identity map given (photo_fwd_idm_kernel)
+        if (k2 > n) n = k2;
     }
     return n * 2 * sizeof(float);
 }
@@ -1790,6 +1809,33 @@ int ds_fused_loss_bwd(const float* warped, const float* target, const float* idt
 }
 
 }  // extern "C"
+
+int ds::fused_loss_fwd_idm_partials(const float* warped, const float* target, const float* idt_loss, int B, int S, int H, int W,
+                                    float* out_loss, uint8_t* aux, void* workspace, size_t workspace_bytes,
+                                    int* waves_per_image, hipStream_t stream) {
+    if (!warped || !target || !idt_loss || !out_loss || !aux || bad_dims(B, S, H, W)) return DS_ERR_INVALID_ARG;
+    if (S > DS_MAX_SOURCES) return DS_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < ds_fused_loss_workspace_bytes(B, H, W)) return DS_ERR_WORKSPACE;
+    const long long HW = (long long)H * W;
+    PhotoFwdParams P{};
+    P.preds = warped; P.target = target;
+    P.pred_stride_b = (long long)S * 3 * HW;
+    P.tgt_stride_b = 3 * HW;
+    P.B = B; P.H = H; P.W = W;
+    P.out = out_loss; P.idt = const_cast<float*>(idt_loss); P.aux = aux; P.wave_partials = (float*)workspace;
+    const Geom g = make_fwd_geom(B, H, W, S, false);
+    P.nbx = g.nbx; P.nby = g.nby; P.RB = g.RB;
+    const dim3 grid(g.nblocks), block(64 * kFwdWaves);
+    switch (S) {
+        case 1: hipLaunchKernelGGL((photo_fwd_idm_kernel<1>), grid, block, 0, stream, P); break;
+        case 2: hipLaunchKernelGGL((photo_fwd_idm_kernel<2>), grid, block, 0, stream, P); break;
+        case 3: hipLaunchKernelGGL((photo_fwd_idm_kernel<3>), grid, block, 0, stream, P); break;
+        default: hipLaunchKernelGGL((photo_fwd_idm_kernel<4>), grid, block, 0, stream, P); break;
+    }
+    DS_CHECK_LAUNCH();
+    *waves_per_image = g.nbx * g.nby;
+    return DS_OK;
+}
 
 int ds::warp_and_identity(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
                           const float* target, int B, int S, int H, int W, float* warped, float* idt_loss,

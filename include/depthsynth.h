@@ -164,10 +164,11 @@ int ds_fused_loss_fb_warp_bwd(const float* K, const float* Kinv, const float* po
                               int S, int H, int W, float* out_loss, uint8_t* aux, float* sums, float* g_warped,
                               float* g_depth, float* g_pose, void* workspace, size_t workspace_bytes, void* stream);
 
-/* The two halves of a loss step in one call each, on the caller's stream: ds_warp_fwd + ds_fused_loss_fwd, and
- * ds_fused_loss_bwd + ds_warp_bwd (train.py:72-88 and its autograd for B targets; source and grid sizes equal).
- * Arguments as in the four calls; g_warped (B,S,3,H,W) is scratch for the backward.  Same launches, half the calls for a
- * host layer that pays per call. */
+/* The two halves of a loss step in one call each, on the caller's stream: the results of ds_warp_fwd + ds_fused_loss_fwd,
+ * and of ds_fused_loss_bwd + ds_warp_bwd (train.py:72-88 and its autograd for B targets; source and grid sizes equal).
+ * Arguments as in the four calls; g_warped (B,S,3,H,W) is scratch for the backward.  Half the calls for a host layer that
+ * pays per call; for S <= 2 the forward half runs as ds_warp_identity_fwd followed by the loss of the warped groups against
+ * that identity map (the same maps bit for bit; the means from another order of the partial sums). */
 size_t ds_loss_step_workspace_bytes(int B, int S, int H, int W);
 int ds_loss_step_fwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
                      const float* target, int B, int S, int H, int W, float* warped, float* out_loss, float* idt_loss,
