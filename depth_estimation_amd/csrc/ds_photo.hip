@@ -1850,11 +1850,11 @@ int ds::warp_and_identity(const float* K, const float* Kinv, const float* pose, 
     P.tgt_stride_b = 3 * HW;
     P.B = B; P.H = H; P.W = W;
     P.out = idt_loss; P.aux = nullptr;
-    // S <= 2: every workgroup is a loss workgroup whose waves also warp (55 / 95 VGPRs at S = 1 / 2: eight / five per CU);
-    // S > 2: warp workgroups and loss workgroups side by side in one launch
+    // S <= 3: every workgroup is a loss workgroup whose waves also warp (eight / five / four per CU at S = 1 / 2 / 3);
+    // S = 4: warp workgroups and loss workgroups side by side in one launch (three sources in the E wave spill)
     // (the chunking is flat in the assumed residency between 4 and 8 per CU, profiles/r02_kb3_warp_identity_one_launch.txt)
-    const bool ew = S <= 2;
-    const Geom gm = ew ? make_fwd_lds_geom(B, H, W, S, S == 1 ? 8 : 5) : make_fwd_geom(B, H, W, S, false);
+    const bool ew = S <= 3;
+    const Geom gm = ew ? make_fwd_lds_geom(B, H, W, S, S == 1 ? 8 : (S == 2 ? 5 : 4)) : make_fwd_geom(B, H, W, S, false);
     P.nbx = gm.nbx; P.nby = gm.nby; P.RB = gm.RB;
     WarpIdtParams Q{};
     Q.K = K; Q.Kinv = Kinv; Q.pose = pose; Q.depth = depth; Q.src = src; Q.warped = warped;
@@ -1871,7 +1871,8 @@ int ds::warp_and_identity(const float* K, const float* Kinv, const float* pose, 
         const dim3 grid(Q.n_loss);
         switch (S) {
             case 1: hipLaunchKernelGGL((warp_idt_kernel<1, true>), grid, block, 0, stream, Q, P); break;
-            default: hipLaunchKernelGGL((warp_idt_kernel<2, true>), grid, block, 0, stream, Q, P); break;
+            case 2: hipLaunchKernelGGL((warp_idt_kernel<2, true>), grid, block, 0, stream, Q, P); break;
+            default: hipLaunchKernelGGL((warp_idt_kernel<3, true>), grid, block, 0, stream, Q, P); break;
         }
     } else {
         const dim3 grid(8 * Q.groups_total);

@@ -76,9 +76,9 @@ int ds_loss_step_fwd(const float* K, const float* Kinv, const float* pose, const
                      const float* target, int B, int S, int H, int W, float* warped, float* out_loss, float* idt_loss,
                      uint8_t* aux, float* sums, void* workspace, size_t workspace_bytes, void* stream) {
     if (B <= 0 || S <= 0 || (long long)B * S > 65535) return DS_ERR_INVALID_ARG;
-    if (S <= 2) {
+    if (S <= 3) {
         // the warp and the identity map from one launch (the loss workgroups' waves warp), then the warped groups' loss
-        // against that map: the same maps as below, 62 instead of 68 us at B=12 192x640
+        // against that map: the same maps as below, 60 instead of 68 us at B=12 S=2 192x640
         if (!sums) return DS_ERR_INVALID_ARG;
         hipStream_t st = (hipStream_t)stream;
         int rc = ds::warp_and_identity(K, Kinv, pose, depth, src, target, B, S, H, W, warped, idt_loss, st);
@@ -192,6 +192,15 @@ int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, co
                            1.0 / ((double)H * W), sums, B, (const float*)pose_partials, wpi, g_pose);
         DS_CHECK_LAUNCH();
         return DS_OK;
+    } else if (S == 3) {
+        // three sources (the reference's SEQ_LEN - 1): the forward as for S <= 2 (warp + identity map in one launch, then
+        // the warped groups against it), the backward unfused (164 VGPRs in the fused kernel: +33 %, profiles/r02_kb4)
+        rc = ds::warp_and_identity(K, Kinv, pose, depth, src, target, B, S, H, W, warped, idt_loss, st);
+        if (rc != DS_OK) return rc;
+        rc = ds::fused_loss_fwd_idm_partials(warped, target, idt_loss, B, S, H, W, out_loss, aux, ws_loss, n_loss, &wpi, st);
+        if (rc != DS_OK) return rc;
+        rc = ds_fused_loss_bwd(warped, target, idt_loss, aux, g_sums, B, S, H, W, g_warped, stream);
+        if (rc != DS_OK) return rc;
     } else {
         rc = ds_warp_fwd(K, Kinv, pose, depth, src, B * S, 3, H, W, H, W, warped, stream);
         if (rc != DS_OK) return rc;

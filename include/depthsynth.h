@@ -167,7 +167,7 @@ int ds_fused_loss_fb_warp_bwd(const float* K, const float* Kinv, const float* po
 /* The two halves of a loss step in one call each, on the caller's stream: the results of ds_warp_fwd + ds_fused_loss_fwd,
  * and of ds_fused_loss_bwd + ds_warp_bwd (train.py:72-88 and its autograd for B targets; source and grid sizes equal).
  * Arguments as in the four calls; g_warped (B,S,3,H,W) is scratch for the backward.  Half the calls for a host layer that
- * pays per call; for S <= 2 the forward half runs as ds_warp_identity_fwd followed by the loss of the warped groups against
+ * pays per call; for S <= 3 the forward half runs as ds_warp_identity_fwd followed by the loss of the warped groups against
  * that identity map (the same maps bit for bit; the means from another order of the partial sums). */
 size_t ds_loss_step_workspace_bytes(int B, int S, int H, int W);
 int ds_loss_step_fwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
