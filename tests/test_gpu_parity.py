@@ -403,7 +403,9 @@ def test_train_step_loss_matches_per_sample_composition(de):
     assert rel_to_max(N(v1.grad), N(v2.grad)) < 1e-4
     # the extras are those of fused_reprojection_loss
     rb = de.fused.fused_reprojection_loss(src, tgt, depth, pose2.detach(), K, Kinv)
-    assert np.array_equal(N(r["loss"]), N(rb["loss"])) and np.array_equal(N(r["aux"]), N(rb["aux"]))
+    # (maps bit for bit; the per-target means come from another order of the partial sums in the fused step: 1e-6)
+    assert np.allclose(N(r["loss"]), N(rb["loss"]), rtol=1e-6, atol=0) and np.array_equal(N(r["aux"]), N(rb["aux"]))
+    assert np.array_equal(N(r["out_loss"]), N(rb["out_loss"])) and np.array_equal(N(r["idt_loss"]), N(rb["idt_loss"]))
     assert np.array_equal(N(r["out_loss"]), N(rb["out_loss"])) and np.array_equal(N(r["warped"]), N(rb["warped"]))
 
 
