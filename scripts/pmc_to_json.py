@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 # bench.py's call names -> the kernels a call launches (finalize kernels: a single wave, left out)
 KERNELS = {"warp_identity": "warp_idt_kernel<2, true>", "loss_fb_warp_bwd": "photo_fb_kernel<2, true>",
-           "loss_fb": "photo_fb_kernel<2, false>", "warp_bwd": "warp_bwd_kernel<3, false>",
+           "loss_fb": "photo_fb_kernel<2, false>", "warp_bwd": "warp_bwd_kernel<3, false, 8>",
            "warp_fwd": "warp_fwd_kernel<3>", "loss_fwd": "photo_fwd_kernel<2, true>", "loss_bwd": "photo_bwd_kernel<2, true>",
            "metrics": "metrics_kernel"}
 
@@ -45,5 +45,19 @@ for wl in ("b12_s2_192x640_fwdbwd", "b64_s2_320x1024_fwdbwd"):
             d[name] = e
     if d:
         res[wl] = d
+# config 3: the finest level's launches, from the single-level passes with --image-grad
+f, w, q = [read(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{c}_imggrad.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ1")]
+d = {}
+for name, kern in (("warp_identity", "warp_idt_kernel<2, true>"), ("loss_fb", "photo_fb_kernel<2, false>"),
+                   ("warp_bwd", "warp_bwd_kernel<3, true, 8>")):
+    e = {}
+    if kern in f and kern in w:
+        e["hbm_bytes"] = int((2 * f[kern]["FETCH_SIZE"] + w[kern]["WRITE_SIZE"]) * 1024)
+    if kern in q and "SQ_INSTS_VALU" in q[kern]:
+        e["valu_wave_insts"] = int(q[kern]["SQ_INSTS_VALU"])
+    if e:
+        d[name] = e
+if d:
+    res["b12_s2_192x640_pyramid4_fwdbwd"] = d
 json.dump(res, open(os.path.join(ROOT, "profiles", "pmc.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
