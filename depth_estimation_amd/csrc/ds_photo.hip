@@ -468,19 +468,20 @@ __global__ __launch_bounds__(64 * kFwdWaves, 4) void photo_fwd_idm_kernel(PhotoF
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// One launch, two kinds of workgroups: the warp (ds_warp_fwd's tiles: gather-bound, short) and the identity loss
-// (photo_fwd_body on the un-warped sources: VALU-bound, long).  Neither depends on the other -- the identity term
-// knows nothing of depth or pose -- so they can share the compute units instead of running one after the other, and
-// the step has one dependent launch less.  Blocks come in groups of eight (one per XCD, so that a workgroup's XCD is
-// the one its index inside its own list implies).  Measured (gpurun_out/r02_kb3_hetero.txt; two launches = 100 %):
-// B=12 192x640 interleaved in proportion 102 %, warp groups first 97 %, loss groups first 99 %; B=64 320x1024 97.4 % /
-// 100.2 % / 98.1 %.  A launch of a few rounds gains from the missing kernel boundary only (the loss workgroups start
-// while the last warp tiles drain); a long one gains a little from sharing.  So: warp first for small launches,
-// interleaved for large ones.
+// The warp and the identity loss (photo_fwd_body on the un-warped sources) in one launch.  Neither depends on the other --
+// the identity term knows nothing of depth or pose.
+//   EW (S <= 3): every workgroup is a loss workgroup and its waves warp the band's rows themselves, the gathers issued a
+//   step ahead of their use (photo_fwd_body).  B=12 S=2 192x640: 35 us against 18 (warp) + 23 (identity loss) as two
+//   launches; the gathers hit the cache lines the same workgroup streams (profiles/r02_kb3_warp_identity_one_launch.txt).
+//   !EW (S = 4): two kinds of workgroups, the warp's tiles (ds_warp_fwd) and the loss workgroups, in groups of eight (one
+//   per XCD, so that a workgroup's XCD is the one its index inside its own list implies).  Two launches = 100 %: B=12
+//   192x640 interleaved in proportion 102 %, warp groups first 97 %, loss groups first 99 %; B=64 320x1024 97.4 % /
+//   100.2 % / 98.1 % -- sharing the CUs gains little beyond the missing kernel boundary.  Warp first for small launches,
+//   interleaved for large ones.
 
 template <int S, bool EW>
 __global__ __launch_bounds__(64 * kFwdWaves, 4) void warp_idt_kernel(WarpIdtParams Q, PhotoFwdParams P) {
-    if (EW) {   // every workgroup is a loss workgroup whose E wave warps the band's rows
+    if (EW) {   // every workgroup is a loss workgroup whose waves warp the band's rows
         photo_fwd_body<S, false, true>(P, (int)blockIdx.x, (int)gridDim.x, &Q);
         return;
     }
