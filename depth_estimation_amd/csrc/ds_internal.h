@@ -66,6 +66,7 @@ DS_HIDDEN int warp_and_identity(const float* K, const float* Kinv, const float* 
                                 hipStream_t stream);
 // forward AND backward of the warped groups in one kernel, given the identity map (ds_photo.hip: photo_fb_kernel); S <= 2
 DS_HIDDEN bool fused_loss_fb_supported(int S);
+DS_HIDDEN bool fused_loss_fbw_supported(int S);   // with the warp's autograd in the fourth wave: also S = 3 (three waves per SIMD)
 DS_HIDDEN size_t fused_loss_fb_workspace_bytes(int B, int H, int W);
 DS_HIDDEN int fused_loss_fb_partials(const float* warped, const float* target, const float* idt_loss, const float* g_sums,
                                      int B, int S, int H, int W, float* out_loss, uint8_t* aux, float* g_warped,

@@ -1651,10 +1651,10 @@ inline Geom make_bwd_geom(int B, int H, int W) {
 }
 
 // Fused forward+backward kernel: one workgroup per (band of 62 output columns, row chunk); 4 workgroups per CU.
-inline Geom make_fb_geom(int B, int H, int W) {
+inline Geom make_fb_geom(int B, int H, int W, int S = 2) {
     Geom g;
     g.nbx = (W + 61) / 62;
-    const long long capacity = simd_count();  // workgroups resident at once: four per CU
+    const long long capacity = S <= 2 ? simd_count() : simd_count() / 4 * 3;  // workgroups resident at once: four per CU (three at S = 3)
     const long long per_chunk = (long long)B * g.nbx;
     const long long nby = pick_chunks(per_chunk, capacity, H, 16);
     g.RB = (H + (int)nby - 1) / (int)nby;
@@ -1889,6 +1889,7 @@ int ds::warp_and_identity(const float* K, const float* Kinv, const float* pose, 
 }
 
 bool ds::fused_loss_fb_supported(int S) { return S >= 1 && S <= 2; }
+bool ds::fused_loss_fbw_supported(int S) { return S >= 1 && S <= 3; }
 
 size_t ds::fused_loss_fb_workspace_bytes(int B, int H, int W) {
     if (B <= 0 || H < 2 || W < 2) return 0;
@@ -1917,7 +1918,7 @@ int ds::fused_loss_fb_partials(const float* warped, const float* target, const f
 
 size_t ds::fused_loss_fbw_workspace_bytes(int B, int S, int H, int W) {
     if (B <= 0 || S <= 0 || H < 2 || W < 2) return 0;
-    const Geom g = make_fb_geom(B, H, W);
+    const Geom g = make_fb_geom(B, H, W, S);
     // per-workgroup loss partials, then per-workgroup pose partials of every (target, source)
     return (size_t)g.nwaves * 2 * sizeof(float) + (size_t)g.nwaves * S * 12 * sizeof(float);
 }
@@ -1930,9 +1931,9 @@ int ds::fused_loss_fbw_partials(const float* K, const float* Kinv, const float* 
     if (!K || !Kinv || !pose || !depth || !src || !warped || !target || !idt_loss || !out_loss || !aux || !g_depth ||
         bad_dims(B, S, H, W) || (long long)B * S > 65535)
         return DS_ERR_INVALID_ARG;
-    if (!fused_loss_fb_supported(S)) return DS_ERR_UNSUPPORTED;
+    if (!fused_loss_fbw_supported(S)) return DS_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < fused_loss_fbw_workspace_bytes(B, S, H, W)) return DS_ERR_WORKSPACE;
-    const Geom g = make_fb_geom(B, H, W);
+    const Geom g = make_fb_geom(B, H, W, S);
     PhotoFbParams P{};
     P.preds = warped; P.target = target; P.idt = idt_loss; P.g_sums = g_sums;
     P.B = B; P.H = H; P.W = W; P.nbx = g.nbx; P.nby = g.nby; P.RB = g.RB;
@@ -1943,7 +1944,8 @@ int ds::fused_loss_fbw_partials(const float* K, const float* Kinv, const float* 
     P.G = warp_geom(H, W, H, W);
     const dim3 grid(g.nblocks), block(64 * kFwdWaves);
     if (S == 1) hipLaunchKernelGGL((photo_fb_kernel<1, true>), grid, block, 0, stream, P);
-    else hipLaunchKernelGGL((photo_fb_kernel<2, true>), grid, block, 0, stream, P);
+    else if (S == 2) hipLaunchKernelGGL((photo_fb_kernel<2, true>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((photo_fb_kernel<3, true>), grid, block, 0, stream, P);
     DS_CHECK_LAUNCH();
     *waves_per_image = g.nbx * g.nby;
     *pose_partials = P.pose_partials;

@@ -119,7 +119,7 @@ int ds_warp_identity_fwd(const float* K, const float* Kinv, const float* pose, c
 }
 
 size_t ds_fused_loss_fb_warp_bwd_workspace_bytes(int B, int S, int H, int W) {
-    return ds::fused_loss_fb_supported(S) ? ds::fused_loss_fbw_workspace_bytes(B, S, H, W) : 0;
+    return ds::fused_loss_fbw_supported(S) ? ds::fused_loss_fbw_workspace_bytes(B, S, H, W) : 0;
 }
 
 int ds_fused_loss_fb_warp_bwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
@@ -143,7 +143,7 @@ size_t ds_loss_step_fwdbwd_workspace_bytes(int B, int S, int H, int W) {
     if (B <= 0 || S <= 0 || H < 2 || W < 2) return 0;
     // both sets of partial sums stay live until the single finalize launch at the end
     const size_t a = loss_partials_bytes(B, H, W) + ds_warp_bwd_workspace_bytes(B * S, H, W);
-    const size_t b = ds::fused_loss_fb_supported(S) ? ds::fused_loss_fbw_workspace_bytes(B, S, H, W) : 0;
+    const size_t b = ds::fused_loss_fbw_supported(S) ? ds::fused_loss_fbw_workspace_bytes(B, S, H, W) : 0;
     return a > b ? a : b;
 }
 
@@ -176,10 +176,11 @@ int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, co
         rc = ds::fused_loss_fb_partials(warped, target, idt_loss, g_sums, B, S, H, W, out_loss, aux, g_warped, ws_loss, n_loss,
                                         &wpi, st);
         if (rc != DS_OK) return rc;
-    } else if (ds::fused_loss_fb_supported(S)) {
-        // the warp and the identity map (un-warped sources against the target: nothing of it depends on depth or pose)
-        // share one launch; then the forward and the backward of the warped groups in ONE kernel: the backward's window
-        // sums are the forward's
+    } else if (ds::fused_loss_fbw_supported(S) && !g_src) {
+        // S <= 3 (S = 3, the reference's SEQ_LEN - 1, at 168 VGPRs = three waves per SIMD: still 9-13 % faster than the unfused
+        // backward, profiles/r02_kb4).  The warp and the identity map (un-warped sources against the target: nothing of it
+        // depends on depth or pose) share one launch; then the forward and the backward of the warped groups in ONE kernel:
+        // the backward's window sums are the forward's
         rc = ds::warp_and_identity(K, Kinv, pose, depth, src, target, B, S, H, W, warped, idt_loss, st);
         if (rc != DS_OK) return rc;
         // ... and that kernel's fourth wave runs the warp's autograd on the rows of d loss / d warped as they are finished:
@@ -193,8 +194,8 @@ int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, co
         DS_CHECK_LAUNCH();
         return DS_OK;
     } else if (S == 3) {
-        // three sources (the reference's SEQ_LEN - 1): the forward as for S <= 2 (warp + identity map in one launch, then
-        // the warped groups against it), the backward unfused (164 VGPRs in the fused kernel: +33 %, profiles/r02_kb4)
+        // three sources with the image gradient: the forward as for S <= 2 (warp + identity map in one launch, then the
+        // warped groups against it), the backward unfused
         rc = ds::warp_and_identity(K, Kinv, pose, depth, src, target, B, S, H, W, warped, idt_loss, st);
         if (rc != DS_OK) return rc;
         rc = ds::fused_loss_fwd_idm_partials(warped, target, idt_loss, B, S, H, W, out_loss, aux, ws_loss, n_loss, &wpi, st);

@@ -157,7 +157,7 @@ int ds_fused_loss_fb(const float* warped, const float* target, const float* idt_
 /* ds_fused_loss_fb with the warp's autograd in the same kernel (its fourth wave takes the rows of d loss / d warped from
  * the loss waves through LDS): everything of a step that follows ds_warp_identity_fwd.  Inputs of ds_fused_loss_fb and
  * ds_warp_bwd (source size = grid size); outputs out_loss, aux, sums, g_depth (B,S,H,W), g_pose (B,S,3,4) and, if
- * g_warped is not NULL, d loss / d warped too (otherwise it never reaches memory).  S <= 2. */
+ * g_warped is not NULL, d loss / d warped too (otherwise it never reaches memory).  S <= 3 (DS_ERR_UNSUPPORTED beyond). */
 size_t ds_fused_loss_fb_warp_bwd_workspace_bytes(int B, int S, int H, int W);
 int ds_fused_loss_fb_warp_bwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
                               const float* warped, const float* target, const float* idt_loss, const float* g_sums, int B,
@@ -180,12 +180,12 @@ int ds_loss_step_bwd(const float* K, const float* Kinv, const float* pose, const
 
 /* The whole loss step -- train.py:72-88 for B targets AND its autograd -- in one call: forward and backward launches
  * back to back on the caller's stream, the two fixed-order finalisations (per-target means, pose gradients) merged into
- * one launch at the end (S <= 2 without g_src: three launches -- warp + identity loss, loss forward + adjoint + the
+ * one launch at the end (S <= 3 without g_src: three launches -- warp + identity loss, loss forward + adjoint + the
  * warp's autograd, finalize; otherwise five).  The loss of train.py:88 is linear in every
  * sums[b][0], so the gradients can be formed before the caller's backward runs: g_sums (B) = d(loss)/d(sums[b][0]), or
  * NULL for a unit upstream gradient -- what loss.backward() passes for the reference's summed loss (train.py:88,103); a
  * caller with another upstream factor scales g_depth and g_pose by it.  Outputs as in the four calls it replaces;
- * g_warped (B,S,3,H,W) is scratch (for S <= 2 the gradient w.r.t. the warped images passes from the loss kernel's
+ * g_warped (B,S,3,H,W) is scratch (for S <= 3 without g_src the gradient w.r.t. the warped images passes from the loss kernel's
  * waves to the warp's autograd inside one kernel and the buffer is left untouched).  g_src (B,S,3,H,W), optional (NULL
  * to skip): the gradient w.r.t. the source images through the warp (cleared and accumulated here; float atomics, as in
  * ds_warp_bwd).  workspace 16-byte aligned, sized by ds_loss_step_fwdbwd_workspace_bytes. */
