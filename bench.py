@@ -38,6 +38,8 @@ WORKLOADS = {
     "b12_s2_192x640_fwdbwd": dict(B=12, S=2, H=192, W=640, scales=1),
     # config 1: "fused forward warp+loss" -- the forward half alone (ds_loss_step_fwd)
     "b12_s2_192x640_fwd": dict(B=12, S=2, H=192, W=640, scales=1, fwd_only=True),
+    # the reference's own sequence length (constants.py: SEQ_LEN = 4, three sources per target)
+    "b8_s3_192x640_fwdbwd": dict(B=8, S=3, H=192, W=640, scales=1),
     # config 3: the same over a 4-scale pyramid (each scale an independent call, K rows scaled per scale)
     # (the backward also scatters the source-image gradient)
     "b12_s2_192x640_pyramid4_fwdbwd": dict(B=12, S=2, H=192, W=640, scales=4, image_grad=True),
@@ -93,7 +95,7 @@ class Scale:
         # The launches of a step, individually callable (per-kernel timing).  Without the image gradient and with S <= 2
         # the step is what ds_loss_step_fwdbwd launches: warp + identity map in one launch, then forward+backward of the
         # warped groups with the warp's autograd in one kernel; otherwise the four classic calls.
-        self.fused_path = S <= 2
+        self.fused_path = S <= 2 or (S == 3 and not image_grad)
         if metrics:
             # test.py:73-81 on the first source's depth map; ground truth U(1,80) with 30 % invalid (zero) pixels
             self.gt = (1 + 79 * torch.rand(B, 1, H, W, generator=g)).to(dev)
