@@ -2,6 +2,8 @@
 (reference file:line in each docstring); every call runs HIP kernels on the tensors' GPU."""
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import ops
@@ -21,21 +23,22 @@ def reprojection_error(preds: torch.Tensor, targets: torch.Tensor) -> torch.Tens
     return ops.ssim_loss(preds, targets)
 
 
-_shared_target_cache = {}  # (data_ptr, version, shape) of the last target stack examined -> bool
+_shared_target_cache = None  # (weak reference to the last target stack examined, its version counter, the answer)
 
 
 def _targets_are_one_image(targets: torch.Tensor) -> bool:
     """train.py:80 builds the target stack with torch.stack([target] * S): S identical copies.  An expanded view shows it
     in its strides; a real stack only in its values, which costs one comparison kernel and a host sync (the reference's
-    loop syncs per sample anyway, train.py:92) -- remembered for the second call on the same tensor (train.py:84-85)."""
+    loop syncs per sample anyway, train.py:92) -- remembered for the second call on the SAME tensor object, unmodified
+    (train.py:84-85); another tensor, even one at the same address, is examined again."""
+    global _shared_target_cache
     if targets.shape[0] == 1 or targets.stride(0) == 0:
         return True
-    key = (targets.data_ptr(), targets._version, tuple(targets.shape))
-    hit = _shared_target_cache.get(key)
-    if hit is None:
-        hit = bool((targets[1:] == targets[:1]).all().item())
-        _shared_target_cache.clear()
-        _shared_target_cache[key] = hit
+    c = _shared_target_cache
+    if c is not None and c[0]() is targets and c[1] == targets._version:
+        return c[2]
+    hit = bool((targets[1:] == targets[:1]).all().item())
+    _shared_target_cache = (weakref.ref(targets), targets._version, hit)
     return hit
 
 

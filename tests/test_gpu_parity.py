@@ -684,6 +684,36 @@ def test_fused_step_differential_fuzz(de):
     assert fuzz_step.run(80, seed=11) == 0
 
 
+def test_reprojection_loss_target_stack_detection(de, oracle):
+    """metrics.reprojection_loss finds out by itself whether the S target slices are one image (train.py:80) and remembers the
+    answer for the same tensor object only: a different stack of the same shape allocated at the address of a freed one
+    must be examined again, and an in-place change of the remembered tensor too."""
+    g = torch.Generator().manual_seed(5)
+    S, H, W = 3, 24, 80
+    preds = torch.rand(S, 3, H, W, generator=g).to(DEV)
+    one = torch.rand(3, H, W, generator=g).to(DEV)
+
+    def ref(p, t):   # min over the sources of each source's error against ITS target slice (metrics.py:54-72)
+        return np.minimum.reduce([oracle.reprojection_loss(N(p[s:s + 1]), N(t[s]))[0] for s in range(S)])
+
+    stack = torch.stack([one] * S)
+    a1 = de.metrics.reprojection_loss(preds, stack)
+    a2 = de.metrics.reprojection_loss(preds, stack)          # the remembered answer
+    assert torch.equal(a1, a2)
+    assert np.array_equal(N(a1).reshape(H, W), ref(preds, stack))
+    ptr = stack.data_ptr()
+    del stack
+    other = torch.rand(S, 3, H, W, generator=g).to(DEV)      # different images; the caching allocator hands the block back
+    b1 = de.metrics.reprojection_loss(preds, other)
+    assert np.array_equal(N(b1).reshape(H, W), ref(preds, other)), other.data_ptr() == ptr
+    same = torch.stack([one] * S)
+    c1 = de.metrics.reprojection_loss(preds, same)
+    same[1].mul_(0.5)                                         # same object, new version: no longer one image
+    c2 = de.metrics.reprojection_loss(preds, same)
+    assert np.array_equal(N(c2).reshape(H, W), ref(preds, same))
+    assert not torch.equal(c1, c2)
+
+
 def test_one_call_step_with_image_gradient(de):
     """ds_loss_step_fwdbwd with g_src: the gradient w.r.t. the source images through the warp (cleared inside the call)
     equals autograd through fused_reprojection_loss(image_grad=True) -- the same scattering kernel on the same
