@@ -496,6 +496,14 @@ def main():
         got = valu_insts / (kern_ms[dom] * 1e-3) / 1e9
         valu = {"achieved": round(got, 1), "peak": round(peak, 1), "unit": "G wave-instr/s", "frac": round(got / peak, 4),
                 "insts_per_launch": valu_insts, "simds": simds}
+        if "valu_fma" in pmc:
+            # `peak` is for plain adds.  Issue cost of the counted mix by the per-instruction costs measured in round 1
+            # (scripts/isa_cost.py: VOP2 add 2.5 cycles, v_fma 3.0, transcendental 8.2; everything else -- moves, multiplies,
+            # compares, selects, VOP3-encoded -- 2.9 on average in these kernels), at the nominal 2.4 GHz
+            rest = valu_insts - pmc["valu_fma"] - pmc["valu_add"] - pmc["valu_trans"]
+            cyc = 3.0 * pmc["valu_fma"] + 2.5 * pmc["valu_add"] + 8.2 * pmc["valu_trans"] + 2.9 * rest
+            valu["mix_issue_ms"] = round(cyc / simds / 2.4e9 * 1e3, 5)
+            valu["frac_of_mix_issue_rate"] = round(valu["mix_issue_ms"] / kern_ms[dom], 4)
     # what binds the dominant kernel: the resource it uses the larger fraction of
     hbm_frac = achieved / HBM_PEAK_GBS
     binding = "valu" if (valu is not None and valu["frac"] > hbm_frac) else "hbm"

@@ -33,7 +33,8 @@ def read(path):
 
 res = {"_comment": __doc__.strip().split("\n", 2)[2].strip() + f"  Source: gpurun_out/pmc_{tag}_* (copies under profiles/)."}
 for wl in ("b12_s2_192x640_fwdbwd", "b64_s2_320x1024_fwdbwd"):
-    f, w, q = [read(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{c}_{wl}.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ1")]
+    f, w, q, q2 = [read(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{c}_{wl}.txt"))
+                   for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ1", "SQ2")]
     d = {}
     for name, kern in KERNELS.items():
         e = {}
@@ -41,6 +42,10 @@ for wl in ("b12_s2_192x640_fwdbwd", "b64_s2_320x1024_fwdbwd"):
             e["hbm_bytes"] = int((2 * f[kern]["FETCH_SIZE"] + w[kern]["WRITE_SIZE"]) * 1024)
         if kern in q and "SQ_INSTS_VALU" in q[kern]:
             e["valu_wave_insts"] = int(q[kern]["SQ_INSTS_VALU"])
+        if kern in q2 and "SQ_INSTS_VALU_FMA_F32" in q2[kern]:   # the instruction mix, for the issue-cost model of bench.py
+            e["valu_fma"] = int(q2[kern]["SQ_INSTS_VALU_FMA_F32"])
+            e["valu_add"] = int(q2[kern]["SQ_INSTS_VALU_ADD_F32"])
+            e["valu_trans"] = int(q2[kern]["SQ_INSTS_VALU_TRANS_F32"])
         if e:
             d[name] = e
     if d:
