@@ -71,6 +71,7 @@ _SIGNATURES = {
     "ds_ingest_resize_u8": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _sz, _fp]),
     "ds_metrics_workspace_bytes": (_sz, [_i, _i, _i]),
     "ds_depth_metrics": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _fp, _sz, _fp]),
+    "ds_depth_metrics_eps": (_i, [_fp, _fp, _i, _i, _i, _f32, _fp, _fp, _fp, _sz, _fp]),
     "ds_depth_metrics_noalloc": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _fp]),
 }
 

@@ -557,10 +557,10 @@ constexpr int kMetPix = 8;  // pixels per thread: two 16-byte loads of each map
 // One valid-or-not pixel into the eight running sums.  The four quotients (|d|/g, d^2/g, p/g, g/p) are IEEE divides; for
 // operands of ordinary magnitude they come bit-identically from one refined reciprocal per denominator (div_by,
 // ds_common.h: 5 instructions each instead of ~12), anything else takes the plain divide.
-__device__ __forceinline__ void metrics_pixel(float p, float g, float (&a)[8]) {
+__device__ __forceinline__ void metrics_pixel(float p, float g, float eps, float (&a)[8]) {
     if (!(g > 0.0f)) return;
     const float df = p - g, sq = df * df, ad = fabsf(df), ap = fabsf(p);
-    const float lg = logf(p + 1e-6f) - logf(g + 1e-6f);
+    const float lg = logf(p + eps) - logf(g + eps);   // metrics.py:122
     float q_ad, q_sq, q_pg, q_gp;
     if (g > 1e-15f && g < 1e15f && ap > 1e-15f && ap < 1e15f) {
         const float rg = rcp_refined(g), rp = rcp_refined(p);
@@ -586,7 +586,7 @@ __device__ __forceinline__ void metrics_pixel(float p, float g, float (&a)[8]) {
 }
 
 __global__ __launch_bounds__(kThreads) void metrics_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
-                                                           int HW, int vec, float* __restrict__ partials) {
+                                                           int HW, int vec, float eps, float* __restrict__ partials) {
     __shared__ float lds[8][kThreads / 64];
     const int b = blockIdx.y;
     float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -599,16 +599,16 @@ __global__ __launch_bounds__(kThreads) void metrics_kernel(const float* __restri
         for (int it = 0; it < kMetPix / 4; ++it) {
             const int i = base + (it * kThreads + threadIdx.x) * 4;
             const float4 p = *reinterpret_cast<const float4*>(P + i), g = *reinterpret_cast<const float4*>(G + i);
-            metrics_pixel(p.x, g.x, a);
-            metrics_pixel(p.y, g.y, a);
-            metrics_pixel(p.z, g.z, a);
-            metrics_pixel(p.w, g.w, a);
+            metrics_pixel(p.x, g.x, eps, a);
+            metrics_pixel(p.y, g.y, eps, a);
+            metrics_pixel(p.z, g.z, eps, a);
+            metrics_pixel(p.w, g.w, eps, a);
         }
     } else {
 #pragma unroll
         for (int it = 0; it < kMetPix; ++it) {
             const int i = base + it * kThreads + threadIdx.x;
-            if (i < HW) metrics_pixel(P[i], G[i], a);
+            if (i < HW) metrics_pixel(P[i], G[i], eps, a);
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -953,13 +953,13 @@ static int scratch_device_ptr(void** out) {
 
 // the launches of ds_depth_metrics; `workspace` is a device pointer of at least ds_metrics_workspace_bytes(B,H,W) bytes,
 // 16-byte aligned.  Every partial and per-image slot that is read has been written by this call: nothing needs clearing.
-static int depth_metrics_launch(const float* pred, const float* gt, int B, int H, int W, float* out, long long* counts,
-                                void* workspace, hipStream_t st) {
+static int depth_metrics_launch(const float* pred, const float* gt, int B, int H, int W, float eps, float* out,
+                                long long* counts, void* workspace, hipStream_t st) {
     const int nb = metric_blocks(H * W);
     const int vec = ((H * W) & 3) == 0 && (((uintptr_t)pred | (uintptr_t)gt) & 15) == 0;
     float* partials = (float*)workspace;
     double* per_image = (double*)(partials + (size_t)B * nb * 8);  // 32 * B * nb bytes in: 8-byte aligned
-    hipLaunchKernelGGL(metrics_kernel, dim3(nb, B), dim3(kThreads), 0, st, pred, gt, H * W, vec, partials);
+    hipLaunchKernelGGL(metrics_kernel, dim3(nb, B), dim3(kThreads), 0, st, pred, gt, H * W, vec, eps, partials);
     DS_CHECK_LAUNCH();
     hipLaunchKernelGGL(metrics_image_kernel, dim3(B), dim3(kThreads), 0, st, partials, nb, 1.0 / ((double)H * W), per_image,
                        counts);
@@ -1169,12 +1169,17 @@ size_t ds_metrics_workspace_bytes(int B, int H, int W) {
     return (size_t)B * metric_blocks(H * W) * 8 * sizeof(float) + (size_t)B * 8 * sizeof(double);
 }
 
-int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, float* out, long long* counts,
-                     void* workspace, size_t workspace_bytes, void* stream) {
+int ds_depth_metrics_eps(const float* pred, const float* gt, int B, int H, int W, float eps, float* out, long long* counts,
+                         void* workspace, size_t workspace_bytes, void* stream) {
     if (!pred || !gt || !out || bad_img(B, 1, H, W)) return DS_ERR_INVALID_ARG;
     if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ds_metrics_workspace_bytes(B, H, W))
         return DS_ERR_WORKSPACE;
-    return depth_metrics_launch(pred, gt, B, H, W, out, counts, workspace, (hipStream_t)stream);
+    return depth_metrics_launch(pred, gt, B, H, W, eps, out, counts, workspace, (hipStream_t)stream);
+}
+
+int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, float* out, long long* counts,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    return ds_depth_metrics_eps(pred, gt, B, H, W, 1e-6f, out, counts, workspace, workspace_bytes, stream);
 }
 
 int ds_depth_metrics_noalloc(const float* pred, const float* gt, int B, int H, int W, float* out, long long* counts,
@@ -1184,7 +1189,7 @@ int ds_depth_metrics_noalloc(const float* pred, const float* gt, int B, int H, i
     void* ws = nullptr;
     const int rc = scratch_device_ptr(&ws);
     if (rc != DS_OK) return rc;
-    return depth_metrics_launch(pred, gt, B, H, W, out, counts, ws, (hipStream_t)stream);
+    return depth_metrics_launch(pred, gt, B, H, W, 1e-6f, out, counts, ws, (hipStream_t)stream);
 }
 
 int ds_ingest_u8(const uint8_t* frames, int N, int H, int W, float* out, void* stream) {

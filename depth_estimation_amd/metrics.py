@@ -2,8 +2,6 @@
 (reference file:line in each docstring); every call runs HIP kernels on the tensors' GPU."""
 from __future__ import annotations
 
-import weakref
-
 import torch
 
 from . import ops
@@ -23,33 +21,35 @@ def reprojection_error(preds: torch.Tensor, targets: torch.Tensor) -> torch.Tens
     return ops.ssim_loss(preds, targets)
 
 
-_shared_target_cache = None  # (weak reference to the last target stack examined, its version counter, the answer)
-
-
-def _targets_are_one_image(targets: torch.Tensor) -> bool:
-    """train.py:80 builds the target stack with torch.stack([target] * S): S identical copies.  An expanded view shows it
-    in its strides; a real stack only in its values, which costs one comparison kernel and a host sync (the reference's
-    loop syncs per sample anyway, train.py:92) -- remembered for the second call on the SAME tensor object, unmodified
-    (train.py:84-85); another tensor, even one at the same address, is examined again."""
-    global _shared_target_cache
-    if targets.shape[0] == 1 or targets.stride(0) == 0:
-        return True
-    c = _shared_target_cache
-    if c is not None and c[0]() is targets and c[1] == targets._version:
-        return c[2]
-    hit = bool((targets[1:] == targets[:1]).all().item())
-    _shared_target_cache = (weakref.ref(targets), targets._version, hit)
-    return hit
-
-
 def reprojection_loss(preds: torch.Tensor, targets: torch.Tensor, shared_target: bool | None = None) -> torch.Tensor:
     """metrics.py:54-72 -- 0.85*SSIM + 0.15*L1, mean over channels, min over dim 0: (S,3,H,W) x2 -> (1,1,H,W).
-    shared_target (not in the reference): True if every targets[s] is the same image (one launch for all sources instead
-    of one per source; same result), None = find out."""
-    if preds.dim() != 4 or targets.shape != preds.shape:
-        raise RuntimeError(f"expected preds and targets (S,3,H,W); got {tuple(preds.shape)}, {tuple(targets.shape)}")
+
+    Argument forms as the reference takes them: rank-3 inputs count as a batch of one (metrics.py:29-30; the L1 term
+    broadcasts), and a dim 0 of size one broadcasts against the other argument's -- ONE target image (3,H,W) or (1,3,H,W)
+    for S predictions, or one prediction against S targets.
+
+    shared_target (not in the reference): True = the caller's promise that every targets[s] holds the same image, as
+    train.py:80's torch.stack([target] * S) does; all S sources then go through one launch that forms the target's window
+    sums once.  None (default): shared exactly when that is visible without reading the data -- one target image, or an
+    expanded view (stride 0 along dim 0); a materialised stack takes one launch per source with a running minimum.  The
+    result is the same bit for bit either way, and no form reads values back to the host.  Hot loops over train.py:84-85
+    should pass shared_target=True (or call fused.train_step_loss, which never builds the stack)."""
+    if preds.dim() == 3:
+        preds = preds.unsqueeze(0)
+    if targets.dim() == 3:
+        targets = targets.unsqueeze(0)
+    if preds.dim() != 4 or targets.dim() != 4 or preds.shape[1:] != targets.shape[1:] or \
+            (preds.shape[0] != targets.shape[0] and 1 not in (preds.shape[0], targets.shape[0])):
+        raise RuntimeError(f"expected preds and targets (S,3,H,W) [or (3,H,W)]; got {tuple(preds.shape)}, {tuple(targets.shape)}")
+    if preds.shape[0] == 1 and targets.shape[0] > 1:
+        preds = preds.expand(targets.shape[0], -1, -1, -1)    # one prediction against S targets (made contiguous below)
     s, c, h, w = preds.shape
-    shared = _targets_are_one_image(targets) if shared_target is None else bool(shared_target)
+    if shared_target is None:
+        shared = targets.shape[0] == 1 or targets.stride(0) == 0
+    else:
+        shared = bool(shared_target)
+    if not shared and targets.shape[0] != s:
+        targets = targets.expand(s, -1, -1, -1)
     tg = targets[0].unsqueeze(0) if shared else targets.unsqueeze(0)
     out, _ = ops.reprojection_loss(preds.unsqueeze(0), tg, shared)
     return out.reshape(1, 1, h, w)
@@ -77,10 +77,8 @@ def rmse(pred_depths, depths: torch.Tensor) -> torch.Tensor:
 
 
 def rmsle(pred_depths: torch.Tensor, depths: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
-    """metrics.py:114-125 (eps is fixed at the reference's default 1e-6 in the kernel)"""
-    if eps != 1e-6:
-        raise RuntimeError("rmsle: only the reference's default eps=1e-6 is supported")
-    return ops.depth_metrics(pred_depths, depths)[1]
+    """metrics.py:114-125"""
+    return ops.depth_metrics(pred_depths, depths, eps=eps)[1]
 
 
 def abs_rel(pred_depths: torch.Tensor, depths: torch.Tensor) -> torch.Tensor:

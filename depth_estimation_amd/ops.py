@@ -465,9 +465,10 @@ def train_step(K, Kinv, pose, depth, src, target, smooth_scale: float, eager_gra
 # ----------------------------------------------------------------------------------------------------
 # forward-only ops
 # ----------------------------------------------------------------------------------------------------
-def depth_metrics(pred, gt, want_counts: bool = False):
+def depth_metrics(pred, gt, want_counts: bool = False, eps: float = 1e-6):
     """pred, gt (B,1,H,W) -> (8,) fp32: rmse, rmsle, abs_rel, sq_rel, delta1, delta2, delta3, n_valid; with want_counts
-    also (B,4) int64: per image the exact counts under the three thresholds and of valid pixels."""
+    also (B,4) int64: per image the exact counts under the three thresholds and of valid pixels.  eps: the offset inside
+    rmsle's logarithms (metrics.py:114)."""
     pred, gt = L.dev_f32(pred.detach(), "pred_depths"), L.dev_f32(gt.detach(), "depths")
     L.same_device(pred, gt)
     if pred.shape != gt.shape or pred.dim() < 3:
@@ -479,8 +480,8 @@ def depth_metrics(pred, gt, want_counts: bool = False):
     counts = torch.empty(b, 4, dtype=torch.int64, device=pred.device) if want_counts else None
     nb = L.lib().ds_metrics_workspace_bytes(b, h, w)
     ws = L.workspace.get(nb, pred.device)
-    L.check(L.lib().ds_depth_metrics(pred.data_ptr(), gt.data_ptr(), b, h, w, out.data_ptr(), L.ptr(counts), ws.data_ptr(), nb,
-                                     L.stream()), "ds_depth_metrics")
+    L.check(L.lib().ds_depth_metrics_eps(pred.data_ptr(), gt.data_ptr(), b, h, w, float(eps), out.data_ptr(), L.ptr(counts),
+                                         ws.data_ptr(), nb, L.stream()), "ds_depth_metrics_eps")
     return (out, counts) if want_counts else out
 
 

@@ -233,6 +233,10 @@ int ds_smooth_batch_bwd(const float* depths, const float* targets, const float* 
 size_t ds_metrics_workspace_bytes(int B, int H, int W);
 int ds_depth_metrics(const float* pred, const float* gt, int B, int H, int W, float* out, long long* counts,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the eps argument of metrics.rmsle (metrics.py:114,122: log(p + eps) - log(g + eps); a Python float added to
+ * an fp32 tensor, hence an fp32 value).  ds_depth_metrics is this call with the reference's default 1e-6. */
+int ds_depth_metrics_eps(const float* pred, const float* gt, int B, int H, int W, float eps, float* out, long long* counts,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ds_depth_metrics without a caller workspace and without any allocation.  No counterpart in the reference: it exists
  * for callers that cannot allocate device memory around the call (code under HIP graph capture, tight serving loops,

@@ -573,7 +573,9 @@ DSO_API void dso_depth_metric_counts(const float* pred, const float* gt, int B, 
     }
 }
 
-DSO_API void dso_depth_metrics(const float* pred, const float* gt, int B, size_t HW, double* out) {
+/* eps: the offset inside the two logarithms of rmsle (metrics.py:114,122; a Python float added to fp32 tensors, i.e.
+ * rounded to fp32 first); the reference's default is 1e-6 */
+DSO_API void dso_depth_metrics_eps(const float* pred, const float* gt, int B, size_t HW, float eps, double* out) {
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int b = 0; b < B; ++b) {
         double s_sq = 0, s_lg = 0, s_ar = 0, s_sr = 0, d1 = 0, d2 = 0, d3 = 0, nv = 0;
@@ -582,7 +584,7 @@ DSO_API void dso_depth_metrics(const float* pred, const float* gt, int B, size_t
             if (!(g > 0.0f)) continue;
             float df = p - g;
             float sq = df * df;
-            float lg = logf(p + 1e-6f) - logf(g + 1e-6f);
+            float lg = logf(p + eps) - logf(g + eps);
             s_sq += (double)sq;
             s_lg += (double)(lg * lg);
             s_ar += (double)(fabsf(df) / g);
@@ -604,6 +606,10 @@ DSO_API void dso_depth_metrics(const float* pred, const float* gt, int B, size_t
     }
     for (int k = 0; k < 7; ++k) out[k] = acc[k] / (double)B;
     out[7] = acc[7];
+}
+
+DSO_API void dso_depth_metrics(const float* pred, const float* gt, int B, size_t HW, double* out) {
+    dso_depth_metrics_eps(pred, gt, B, HW, 1e-6f, out);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -39,6 +39,7 @@ def lib() -> C.CDLL:
             build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.dso_depth_metrics.argtypes = [_f32p, _f32p, C.c_int, C.c_size_t, _f64p]
+        _lib.dso_depth_metrics_eps.argtypes = [_f32p, _f32p, C.c_int, C.c_size_t, C.c_float, _f64p]
         _lib.dso_depth_metric_counts.argtypes = [_f32p, _f32p, C.c_int, C.c_size_t, C.POINTER(C.c_longlong)]
         _lib.dso_depth_from_costs.argtypes = [_f32p, C.c_int, C.c_int, C.c_size_t, C.c_int, _f32p]
         _lib.dso_regularization_term.restype = C.c_double
@@ -177,13 +178,13 @@ def regularization_term(depths, targets, want_grad: bool = False, g_scale: float
     return (float(val), g) if want_grad else float(val)
 
 
-def depth_metrics(pred, gt) -> dict:
-    """a11-a15: pred, gt (B,1,H,W)."""
+def depth_metrics(pred, gt, eps: float = 1e-6) -> dict:
+    """a11-a15: pred, gt (B,1,H,W); eps = the offset in rmsle's logarithms (metrics.py:114)."""
     pred, gt = _f(pred), _f(gt)
     B = pred.shape[0]
     hw = pred.size // B
     out = np.zeros(8, np.float64)
-    lib().dso_depth_metrics(_p(pred), _p(gt), B, hw, out.ctypes.data_as(_f64p))
+    lib().dso_depth_metrics_eps(_p(pred), _p(gt), B, hw, float(eps), out.ctypes.data_as(_f64p))
     keys = ("rmse", "rmsle", "abs_rel", "sq_rel", "delta1", "delta2", "delta3", "n_valid")
     return dict(zip(keys, out.tolist()))
 

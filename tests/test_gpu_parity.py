@@ -684,34 +684,55 @@ def test_fused_step_differential_fuzz(de):
     assert fuzz_step.run(80, seed=11) == 0
 
 
-def test_reprojection_loss_target_stack_detection(de, oracle):
-    """metrics.reprojection_loss finds out by itself whether the S target slices are one image (train.py:80) and remembers the
-    answer for the same tensor object only: a different stack of the same shape allocated at the address of a freed one
-    must be examined again, and an in-place change of the remembered tensor too."""
-    g = torch.Generator().manual_seed(5)
-    S, H, W = 3, 24, 80
-    preds = torch.rand(S, 3, H, W, generator=g).to(DEV)
-    one = torch.rand(3, H, W, generator=g).to(DEV)
+def test_reprojection_loss_argument_forms(de, oracle):
+    """metrics.reprojection_loss takes what the reference takes (metrics.py:29-30,62-72): a materialised target stack
+    (train.py:80; one launch per source, no value is read back to the host), an expanded view or a single target image (one
+    launch), rank-3 inputs, one prediction against S targets -- against reference-made vectors (tests/golden/
+    facade_vectors.npz, tools/gen_golden.py facade) bit for bit, and a stack whose slices differ against the oracle."""
+    gold = load_golden("facade_vectors")
+    d = load_golden("synth_oov_24x80")
+    warped, target, tstack = T(d["warped"]), T(d["target"]), T(gold["tstack"])
+    S, _, H, W = warped.shape
+    stack = torch.stack([target] * S)
+    forms = [de.metrics.reprojection_loss(warped, stack),                              # train.py:80,84
+             de.metrics.reprojection_loss(warped, stack, shared_target=True),
+             de.metrics.reprojection_loss(warped, target[None].expand(S, -1, -1, -1)),
+             de.metrics.reprojection_loss(warped, target),                             # (S,C,H,W) against (C,H,W)
+             de.metrics.reprojection_loss(warped, target[None])]
+    for f in forms:
+        assert f.shape == (1, 1, H, W) and np.array_equal(N(f), d["out_loss"]) and np.array_equal(N(f), gold["rank3_target"])
+    assert np.array_equal(N(de.metrics.reprojection_loss(warped[0], target)), gold["rank3_both"])
+    assert np.array_equal(N(de.metrics.reprojection_loss(warped[0], tstack)), gold["rank3_pred"])
+    got = de.metrics.reprojection_loss(warped, tstack)
+    assert np.array_equal(N(got), gold["rank4_distinct_targets"])
+    want = np.minimum.reduce([oracle.reprojection_loss(N(warped[s:s + 1]), N(tstack[s]))[0] for s in range(S)])
+    assert np.array_equal(N(got).reshape(H, W), want)
+    assert np.array_equal(N(de.metrics.reprojection_error(warped[0], target)), gold["err_rank3"])
+    # in-place changes of a stack are seen (nothing is remembered between calls)
+    stack[1].mul_(0.5)
+    c2 = de.metrics.reprojection_loss(warped, stack)
+    want = np.minimum.reduce([oracle.reprojection_loss(N(warped[s:s + 1]), N(stack[s]))[0] for s in range(S)])
+    assert np.array_equal(N(c2).reshape(H, W), want)
+    # gradients flow through every form (rank-3 prediction against S targets: summed over the broadcast)
+    p = warped[0].clone().requires_grad_(True)
+    de.metrics.reprojection_loss(p, tstack).sum().backward()
+    q = warped[0][None].expand(S, -1, -1, -1).clone().requires_grad_(True)
+    de.metrics.reprojection_loss(q, tstack).sum().backward()
+    assert rel_to_max(N(p.grad), N(q.grad.sum(0))) < 1e-6
 
-    def ref(p, t):   # min over the sources of each source's error against ITS target slice (metrics.py:54-72)
-        return np.minimum.reduce([oracle.reprojection_loss(N(p[s:s + 1]), N(t[s]))[0] for s in range(S)])
 
-    stack = torch.stack([one] * S)
-    a1 = de.metrics.reprojection_loss(preds, stack)
-    a2 = de.metrics.reprojection_loss(preds, stack)          # the remembered answer
-    assert torch.equal(a1, a2)
-    assert np.array_equal(N(a1).reshape(H, W), ref(preds, stack))
-    ptr = stack.data_ptr()
-    del stack
-    other = torch.rand(S, 3, H, W, generator=g).to(DEV)      # different images; the caching allocator hands the block back
-    b1 = de.metrics.reprojection_loss(preds, other)
-    assert np.array_equal(N(b1).reshape(H, W), ref(preds, other)), other.data_ptr() == ptr
-    same = torch.stack([one] * S)
-    c1 = de.metrics.reprojection_loss(preds, same)
-    same[1].mul_(0.5)                                         # same object, new version: no longer one image
-    c2 = de.metrics.reprojection_loss(preds, same)
-    assert np.array_equal(N(c2).reshape(H, W), ref(preds, same))
-    assert not torch.equal(c1, c2)
+def test_rmsle_eps(de, oracle):
+    """metrics.rmsle(pred, gt, eps) for eps other than the default (metrics.py:114,122) against the reference's values
+    (facade_vectors.npz) and the oracle, 1e-4 relative."""
+    gold = load_golden("facade_vectors")
+    d = load_golden("metrics_3x40x96")
+    pred, gt = T(d["pred"]), T(d["gt"])
+    for tag, eps in (("1e-3", 1e-3), ("0.5", 0.5), ("0", 0.0)):
+        v = float(de.metrics.rmsle(pred, gt, eps=eps))
+        want = float(gold["rmsle_eps_" + tag])
+        assert abs(v - want) < 1e-4 * abs(want), tag
+        assert abs(v - oracle.depth_metrics(d["pred"], d["gt"], eps=eps)["rmsle"]) < 1e-5 * abs(want)
+    assert abs(float(de.metrics.rmsle(pred, gt)) - float(d["rmsle"])) < 1e-4 * float(d["rmsle"])
 
 
 def test_one_call_step_with_image_gradient(de):

@@ -197,3 +197,47 @@ def test_pil_resize_restatement(oracle):
         assert np.array_equal(oracle.pil_resize_bilinear_u8(a, (ho, wo)), want), (H, W, ho, wo)
     with pytest.raises(ValueError):
         oracle.pil_resize_bilinear_u8(np.zeros((100, 7, 3), np.uint8), (3, 50))   # 33x down: beyond the 64-tap limit
+
+
+def test_plane_sweep_at_the_reference_shape(oracle):
+    """train.py:49-60 as the reference runs it (constants.COST_* grid 96x320, sources 192x640, 80 SID planes): the oracle's
+    plane images and cost volume bit for bit (CRC), the candidate depth to 1e-6 and its bicubic up-resize to 1e-5, against
+    tests/golden/plane_sweep_96x320.npz (tools/gen_golden.py plane_sweep_full)."""
+    d = load_golden("plane_sweep_96x320")
+    fr = real_frames("real_192x640")
+    src, tgt = fr[:-1], fr[-1]
+    H, W = 96, 320
+    pm = oracle.pose_from_vec(d["pose_vec"])
+    assert np.abs(pm - d["pose_mats"]).max() <= 2e-7
+    small = oracle.resize_bilinear(tgt, (H, W))
+    cvs = []
+    for s in range(3):
+        syn = oracle.synthesize_from_depths(d["K"], d["Kinv"], d["pose_mats"][s], d["depths"], W, H, src[s])
+        assert crc32(syn) == int(d["crc_synth"][s])                      # synthesis.py:57-80
+        cvs.append(oracle.cost_volume(small, syn))
+    cvs = np.stack(cvs)
+    # the target at cost resolution comes from the oracle's interpolate (1e-6 of torch's): costs to 1e-6, not CRC
+    assert np.abs(cvs[:, ::8, ::4, ::4] - d["sub_cost"]).max() < 1e-6    # metrics.py:5-18
+    cand = oracle.depth_from_costs(cvs)
+    assert np.abs(cand - d["cand"]).max() < 1e-5                         # synthesis.py:119-138
+    full = oracle.resize_bicubic(d["cand"], (192, 640))
+    assert np.abs(full[..., ::4, ::4] - d["sub_full"]).max() < 1e-5      # train.py:60
+
+
+def test_facade_vectors(oracle):
+    """rmsle with a non-default eps (metrics.py:114) and reprojection_loss on one prediction / distinct targets
+    (metrics.py:54-72 with broadcasting) against the reference-made vectors."""
+    g = load_golden("facade_vectors")
+    m = load_golden("metrics_3x40x96")
+    for tag, eps in (("1e-3", 1e-3), ("0.5", 0.5), ("0", 0.0)):
+        want = float(g["rmsle_eps_" + tag])
+        assert abs(oracle.depth_metrics(m["pred"], m["gt"], eps=eps)["rmsle"] - want) < 1e-5 * abs(want), tag
+    d = load_golden("synth_oov_24x80")
+    S, _, H, W = d["warped"].shape
+    one = oracle.reprojection_loss(d["warped"][:1], d["target"])[0]
+    assert np.array_equal(one, g["rank3_both"].reshape(H, W))
+    per = [oracle.reprojection_loss(d["warped"][s:s + 1], g["tstack"][s])[0] for s in range(S)]
+    assert np.array_equal(np.minimum.reduce(per), g["rank4_distinct_targets"].reshape(H, W))
+    per0 = [oracle.reprojection_loss(d["warped"][:1], g["tstack"][s])[0] for s in range(S)]
+    assert np.array_equal(np.minimum.reduce(per0), g["rank3_pred"].reshape(H, W))
+    assert np.array_equal(oracle.ssim(d["warped"][:1], d["target"][None]), g["err_rank3"])

@@ -332,8 +332,66 @@ def case_raw_frame(name):
     print(name, raw.shape)
 
 
+def case_facade(name):
+    """Round 3: argument forms of metrics.py the drop-in must accept like the reference does -- rmsle with a non-default
+    eps (metrics.py:114), reprojection_loss on rank-3 inputs (metrics.py:29-30 unsqueeze them; the L1 term broadcasts)
+    and on one target image against S predictions / one prediction against S targets (plain broadcasting)."""
+    m = np.load(os.path.join(OUT, "metrics_3x40x96.npz"))
+    pred, gt = torch.from_numpy(m["pred"]), torch.from_numpy(m["gt"])
+    rec = {}
+    for tag, eps in (("1e-3", 1e-3), ("0.5", 0.5), ("0", 0.0)):
+        rec["rmsle_eps_" + tag] = np.array(ref_metrics.rmsle(pred, gt, eps=eps).item(), dtype=np.float64)
+    d = np.load(os.path.join(OUT, "synth_oov_24x80.npz"))
+    warped, target = torch.from_numpy(d["warped"]), torch.from_numpy(d["target"])      # (3,3,24,80), (3,24,80)
+    S = warped.shape[0]
+    rec["rank3_both"] = npf(ref_metrics.reprojection_loss(warped[0], target))           # (C,H,W) x2 -> (1,1,H,W)
+    rec["rank3_target"] = npf(ref_metrics.reprojection_loss(warped, target))            # (S,C,H,W), (C,H,W)
+    assert int(crc(rec["rank3_target"])) == int(d["crc_out_loss"])                      # == the stacked-target call
+    tstack = torch.stack([target, warped[1], target.flip(-1)])                          # three different target images
+    rec["tstack"] = npf(tstack)
+    rec["rank3_pred"] = npf(ref_metrics.reprojection_loss(warped[0], tstack))           # (C,H,W), (S,C,H,W)
+    rec["rank4_distinct_targets"] = npf(ref_metrics.reprojection_loss(warped, tstack))
+    rec["err_rank3"] = npf(ref_metrics.reprojection_error(warped[0], target))           # (1,C,H,W)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(name, {k: (float(v) if v.ndim == 0 else v.shape) for k, v in rec.items()})
+
+
+def case_plane_sweep_full(name):
+    """train.py:49-60 at the reference's real shape: sources 192x640 (frames 0-2 of real_192x640_frames_u8), target frame
+    3, cost grid COST_HEIGHT x COST_WIDTH = 96x320 with constants.COST_INTRINSIC_MAT / _INV, all 80 planes of
+    constants.DEPTHS.  Stores the candidate depths (S,1,96,320) and every 4th row/column of their bicubic up-resize."""
+    u8 = np.load(os.path.join(OUT, "real_192x640_frames_u8.npz"))["frames"]
+    imgs = frames_to_float(u8)
+    src, target = imgs[:-1].contiguous(), imgs[-1].contiguous()
+    K, Kinv = ref_constants.COST_INTRINSIC_MAT, ref_constants.COST_INTRINSIC_INV
+    H, W = ref_constants.COST_HEIGHT, ref_constants.COST_WIDTH
+    K2, Kinv2 = intrinsics(W, H)
+    assert torch.equal(K, K2) and torch.equal(Kinv, Kinv2)        # the restated intrinsics ARE the reference's
+    pose_vec = torch.tensor([[0.004, -0.006, 0.002, 0.25, -0.01, 0.6],
+                             [-0.003, 0.002, 0.001, -0.3, 0.01, -0.5],
+                             [0.001, 0.001, -0.002, 0.1, 0.0, 1.0]])
+    pose = ref_synthesis.construct_pose_batch(pose_vec)
+    depths = ref_constants.DEPTHS
+    synth = [ref_synthesis.synthesize_from_depths(K, Kinv, pm, depths, W, H, s) for pm, s in zip(pose, src)]
+    tgt_small = torch.nn.functional.interpolate(target.unsqueeze(0), size=(H, W), mode="bilinear")
+    cvs = torch.stack([ref_metrics.cost_volumes(tgt_small, s) for s in synth])
+    cand = ref_synthesis.depth_from_costs(cvs)
+    full = torch.nn.functional.interpolate(cand, size=(ref_constants.HEIGHT, ref_constants.WIDTH), mode="bicubic")
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), pose_vec=npf(pose_vec), pose_mats=npf(pose), K=npf(K), Kinv=npf(Kinv),
+                        depths=np.asarray(depths, dtype=np.float64), cand=npf(cand), sub_full=npf(full[..., ::4, ::4]),
+                        crc_synth=np.array([int(crc(npf(s))) for s in synth], dtype=np.uint32),
+                        crc_cost=crc(npf(cvs)), sub_cost=npf(cvs[:, ::8, ::4, ::4]))
+    print(name, "cand range", cand.min().item(), cand.max().item(), "std", cand.std().item())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["facade"]:                                # round 3; reads two fixtures, rewrites none
+        case_facade("facade_vectors")
+        return
+    if sys.argv[1:] == ["plane_sweep_full"]:                      # round 3; reads one fixture, rewrites none
+        case_plane_sweep_full("plane_sweep_96x320")
+        return
     if sys.argv[1:] == ["resize"]:                                # added later; leaves the other fixtures untouched
         case_resize("resize_vectors")
         return
