@@ -45,9 +45,15 @@ WORKLOADS = {
     "b12_s2_192x640_pyramid4_fwdbwd": dict(B=12, S=2, H=192, W=640, scales=4, image_grad=True),
     # config 4: the HBM-resident-set-exceeds-cache case; the step ends with the depth-metrics reduction on (B,1,H,W)
     "b64_s2_320x1024_fwdbwd": dict(B=64, S=2, H=320, W=1024, scales=1, metrics=True),
+    # train.py:49-60 for a batch (not in the headline): target -> 96x320 (bilinear), 80-plane sweep of the
+    # 192x640 sources with the fused cost volume + soft arg-min, candidate depth -> 192x640 (bicubic); forward only
+    "b12_s2_sweep80_96x320": dict(B=12, S=2, H=192, W=640, scales=1, sweep=dict(D=80, h=96, w=320)),
     # config 5: the whole train.py step (stand-in networks, fused loss path, gradient all-reduce, clip, Adam)
     "full_step": dict(B=2, S=3, H=192, W=640, scales=1),
 }
+# what the default line also reports (round-2 verdict item 2): every other config, joined, one stream, <= ~1 s each
+ALSO = ("b12_s2_192x640_fwd", "b8_s3_192x640_fwdbwd", "b12_s2_192x640_pyramid4_fwdbwd", "b64_s2_320x1024_fwdbwd",
+        "b12_s2_sweep80_96x320")
 METRIC = "warped px/s (Gpix/s) fwd+bwd reproj loss @192x640, % HBM roofline, 1-8 GPU"
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 SPIN_UP_S = 0.3              # untimed steps before the warm-up: the device leaves its idle power state (see main())
@@ -107,6 +113,7 @@ class Scale:
         self.ws_fb_n = self.lib.ds_fused_loss_fb_warp_bwd_workspace_bytes(B, S, H, W)
         self.ws_fb = torch.empty(max(self.ws_fb_n, 16), dtype=torch.uint8, device=dev)
         px, tp = self.N * H * W, B * H * W
+        self.units = px                                          # warped pixels per step
         warp_bwd = lambda st: lib.ds_warp_bwd(p(self.K), p(self.Kinv), p(self.pose), p(self.depth), p(self.src),  # noqa: E731
                                               p(self.g_warped), N, 3, H, W, H, W, p(self.g_depth), p(self.g_pose),
                                               p(self.g_src), p(self.ws_warp), self.ws_warp_n, st)
@@ -206,9 +213,65 @@ class Scale:
                 self.L.check(rc, name)
 
 
+class Sweep:
+    """train.py:49-60 for B targets x S sources through the C ABI with pre-allocated outputs: ds_resize_bilinear ->
+    ds_plane_sweep_depth_batch -> ds_resize_bicubic.  Unit of work: a plane pixel (one source warped onto one plane at one
+    cost-grid pixel), B*S*D*h*w of them per step."""
+
+    def __init__(self, de, B, S, H, W, D, h, w, dev, seed):
+        import ctypes
+        import numpy as np
+        from depth_estimation_amd import _lib as L
+        self.L, self.lib = L, L.lib()
+        self.B, self.S, self.H, self.W, self.N = B, S, H, W, B * S
+        self.D, self.h, self.w = D, h, w
+        g = torch.Generator().manual_seed(seed)
+        f = dict(dtype=torch.float32, device=dev)
+        self.src = torch.rand(B, S, 3, H, W, generator=g).to(dev)
+        self.tgt = torch.rand(B, 3, H, W, generator=g).to(dev)
+        vec = (0.01 * torch.randn(B * S, 6, generator=g)).to(dev)
+        self.pose = de.ops.pose_from_vec(vec).contiguous()
+        K, Kinv = de.fused.intrinsics(w, h)                       # constants.py:33-37: intrinsics of the COST grid
+        self.K, self.Kinv = K.to(dev), Kinv.to(dev)
+        self.depths = np.ascontiguousarray(
+            np.array([np.exp((x + 1) * np.log(2) / D) - 1 for x in range(D)]) * 80.0, dtype=np.float64)   # constants.py:19
+        self.dp = self.depths.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        self.small = torch.empty(B, 3, h, w, **f)
+        self.cand = torch.empty(B, S, 1, h, w, **f)
+        self.full = torch.empty(B, S, 1, H, W, **f)
+        p = lambda t: t.data_ptr()  # noqa: E731
+        lib = self.lib
+        self.calls = {
+            "resize_bilinear": lambda st: lib.ds_resize_bilinear(p(self.tgt), B * 3, H, W, h, w, p(self.small), st),
+            "plane_sweep": lambda st: lib.ds_plane_sweep_depth_batch(p(self.K), p(self.Kinv), p(self.pose), self.dp, D,
+                                                                     p(self.src), p(self.small), B, S, 3, H, W, h, w, 1,
+                                                                     p(self.cand), st),
+            "resize_bicubic": lambda st: lib.ds_resize_bicubic(p(self.cand), B * S, h, w, H, W, p(self.full), st),
+        }
+        self.names = tuple(self.calls)
+        # SURVEY 8d "Plane sweep": per source the sampled source REGION (the sweep normalises with the source dims, so a
+        # 96x320-unit grid only reaches the top-left h x w texels, synthesis.py:49) + the small target read, depth written
+        self.alg_bytes = {
+            "resize_bilinear": B * 3 * (H * W + h * w) * 4,
+            "plane_sweep": self.N * (3 * h * w + 3 * h * w + h * w) * 4,
+            "resize_bicubic": self.N * (h * w + H * W) * 4,
+        }
+        self.step_bytes = sum(self.alg_bytes.values())
+        self.units = self.N * D * h * w
+
+    def step(self, st, separate=False):
+        for name in self.names:
+            rc = self.calls[name](st)
+            if rc != 0:
+                self.L.check(rc, name)
+
+
 def build_problem(de, wl, dev, rank, image_grad, parts=1):
     """One Scale per (pyramid level, sub-batch).  With parts > 1 the B targets of a level are split into `parts`
     independent sub-batches (own buffers, own workspaces), which the pipelined variant launches on `parts` HIP streams."""
+    if "sweep" in wl:
+        sw = wl["sweep"]
+        return [Sweep(de, wl["B"], wl["S"], wl["H"], wl["W"], sw["D"], sw["h"], sw["w"], dev, 1000 * rank)]
     scales = []
     for i in range(wl["scales"]):
         # small pyramid levels are launch-bound: splitting them only adds launches
@@ -244,6 +307,29 @@ def cpu_baseline(wl, budget_s=8.0):
     pose = o.pose_from_vec((0.01 * rng.standard_normal((S, 6))).astype(np.float32))
     from depth_estimation_amd.fused import intrinsics
     K, Kinv = [a.numpy() for a in intrinsics(W, H)]
+
+    if "sweep" in wl:
+        sw = wl["sweep"]
+        Kc, Kcinv = [a.numpy() for a in intrinsics(sw["w"], sw["h"])]
+        planes = np.array([np.exp((x + 1) * np.log(2) / sw["D"]) - 1 for x in range(sw["D"])]) * 80.0
+
+        def one_source():          # train.py:49-60 for one source of one target
+            small = o.resize_bilinear(tgt, (sw["h"], sw["w"]))
+            syn = o.synthesize_from_depths(Kc, Kcinv, pose[0], planes, sw["w"], sw["h"], src[0])
+            cand = o.depth_from_costs(o.cost_volume(small, syn)[None])
+            o.resize_bicubic(cand, (H, W))
+
+        cores = host_threads()
+        o.set_threads(cores)
+        one_source()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            one_source()
+            n += 1
+        dt = time.perf_counter() - t0
+        return dict(value=n * sw["D"] * sw["h"] * sw["w"] / dt / 1e9, unit="G plane-px/s", cores=cores, kind="port",
+                    sample=f"{n} sources x {sw['D']} planes at {sw['h']}x{sw['w']} from {H}x{W} (resize, sweep, cost volume, soft "
+                           f"arg-min, resize) in {dt:.1f} s on {cores} threads, oracle/ds_oracle.c; os.cpu_count() = {os.cpu_count()}")
 
     def one_sample():
         warped = np.stack([o.warp(K, Kinv, pose[s], depth[s], src[s], H, W) for s in range(S)])
@@ -317,6 +403,71 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def make_step(scales, main_stream, dev, fork):
+    """The step of a workload on `main_stream`.  fork: a pyramid's levels are independent problems and the coarse ones
+    cannot fill the chip (24x80 x 12 targets: 26 us for three launches that are all latency), so inside every step the levels
+    below the finest are forked onto side streams and joined again before the step ends: the next step still starts only
+    after everything of this one has finished."""
+    st = main_stream.cuda_stream
+    if not fork or len(scales) < 2:
+        def step_one_stream():
+            for sc in scales:
+                sc.step(st)
+        return step_one_stream
+    side = [torch.cuda.Stream(device=dev) for _ in scales[1:]]
+    ev_start = torch.cuda.Event()
+    ev_done = [torch.cuda.Event() for _ in side]
+
+    def step_forked():
+        ev_start.record(main_stream)
+        for sc, s_, e_ in zip(scales[1:], side, ev_done):
+            s_.wait_event(ev_start)
+            sc.step(s_.cuda_stream)
+            e_.record(s_)
+        scales[0].step(st)
+        for e_ in ev_done:
+            main_stream.wait_event(e_)
+    return step_forked
+
+
+def quick_line(de, name, dev, main_stream, budget_s=0.8):
+    """One of the other workloads, joined, on the bench's stream: ~0.15 s of untimed steps, then as many timed steps as fit
+    budget_s.  For the default line's `also` object; the workload's own full line comes from --workload NAME."""
+    wl = WORKLOADS[name]
+    scales = build_problem(de, wl, dev, 0, wl.get("image_grad", False), 1)
+    res = {}
+    for tag, fork in (("one_stream", False),) + ((("forked_levels", True),) if wl["scales"] > 1 else ()):
+        step = make_step(scales, main_stream, dev, fork)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.15:
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - c0) / 5
+        n = max(5, min(5000, int(budget_s / max(per, 1e-6))))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        units, nbytes = sum(sc.units for sc in scales), sum(sc.step_bytes for sc in scales)
+        res[tag] = {"value": round(units / dt / 1e9, 4), "ms_per_step": round(dt * 1e3, 5), "steps": n,
+                    "step_alg_bytes": nbytes, "step_frac_of_hbm_peak": round(nbytes / dt / 1e9 / HBM_PEAK_GBS, 4)}
+    out = res["one_stream"]
+    out["unit"] = "G plane-px/s" if "sweep" in wl else "Gpix/s"
+    out["launch"] = "one stream, every step ordered after the previous one"
+    if "forked_levels" in res:
+        out["forked_levels"] = res["forked_levels"]
+    del scales
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -335,6 +486,8 @@ def main():
                     help="pyramid workloads: all levels one after the other on the main stream (default: coarse levels forked "
                          "onto side streams and joined inside every step)")
     ap.add_argument("--dry", action="store_true", help="launcher / rendezvous check on the CPU (gloo), no kernels")
+    ap.add_argument("--no-also", action="store_true",
+                    help="default workload at N=1: skip the short joined runs of the other workloads (the `also` object)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -347,6 +500,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.dry:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.workload == "full_step":     # the config-5 harness itself over gloo, torch stand-ins for the hot path
+            from scripts import full_step
+            return full_step.main(args, rank, local_rank, world, dry=True)
         return dry_run(args, rank, world)
     if args.workload == "full_step":
         from scripts import full_step
@@ -371,30 +527,9 @@ def main():
     torch.cuda.set_stream(main_stream)
     st = torch.cuda.current_stream().cuda_stream
 
-    # A pyramid's levels are independent problems, and the coarse ones cannot fill the chip (24x80 x 12 targets: 26 us for
-    # three launches that are all latency).  Inside every step the levels below the finest are forked onto side streams and
-    # joined again before the step ends: the next step still starts only after everything of this one has finished.
     fork_levels = len(scales) > 1 and not args.levels_one_stream
-    if fork_levels:
-        side = [torch.cuda.Stream(device=dev) for _ in scales[1:]]
-        ev_start = torch.cuda.Event()
-        ev_done = [torch.cuda.Event() for _ in side]
-
-    def step_one_stream():
-        for sc in scales:
-            sc.step(st)
-
-    def step_forked():
-        ev_start.record(main_stream)
-        for sc, s_, e_ in zip(scales[1:], side, ev_done):
-            s_.wait_event(ev_start)
-            sc.step(s_.cuda_stream)
-            e_.record(s_)
-        scales[0].step(st)
-        for e_ in ev_done:
-            main_stream.wait_event(e_)
-
-    step = step_forked if fork_levels else step_one_stream
+    step_one_stream = make_step(scales, main_stream, dev, False)
+    step = make_step(scales, main_stream, dev, fork_levels)
 
     def barrier():
         torch.cuda.synchronize()
@@ -405,6 +540,21 @@ def main():
     # ~10 ms of kernels run at lower clocks (measured: 200 steps after 20 warm-up steps read 7 % slower than after 200 or
     # more, profiles/r02_warmup_sensitivity.txt).  Untimed, the same steps, SPIN_UP_S seconds; then the W warm-up steps
     # and the K timed steps of the contract.
+    no_spin = None
+    if args.spin_up > 0:
+        # what the same W + K steps read WITHOUT the spin-up (a fresh process, device in its idle power state)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        n0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        no_spin = time.perf_counter() - n0
+        if dist is not None:
+            t = torch.tensor([no_spin], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            no_spin = float(t.item())
     s0 = time.perf_counter()
     while time.perf_counter() - s0 < args.spin_up:
         for _ in range(50):
@@ -423,8 +573,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    warped_px_rank = sum(sc.N * sc.H * sc.W for sc in scales)
+    warped_px_rank = sum(sc.units for sc in scales)
     value = world * warped_px_rank * args.steps / elapsed / 1e9
+    # N > 1: what the process group itself saw (a SUM of ones over the ranks must read N) and what the only cross-rank
+    # traffic a trainer on this path has costs -- one all-reduce of the <= 8 loss / metric scalars (dist.reduce_scalars)
+    group = None
+    if dist is not None:
+        ones = torch.ones(8, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones)
+        ranks_summed = int(ones[0].item())
+        buf = torch.zeros(8, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        group = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks_summed": ranks_summed,
+                 "comm_ms": round((time.perf_counter() - c0) / 20 * 1e3, 4),
+                 "comm": "all-reduce of 8 fp32 scalars (loss / metric sums); no collective on the data path"}
     levels_one_stream = None
     if fork_levels and rank == 0:   # the same steps with every level on the main stream, for comparison
         for _ in range(args.warmup):
@@ -510,7 +676,7 @@ def main():
 
     # the un-joined variant (round 1's headline): independent sub-batches on their own streams, pipelined across steps
     pipelined = None
-    if rank == 0 and args.pipelined > 1 and wl["B"] >= args.pipelined:
+    if rank == 0 and args.pipelined > 1 and wl["B"] >= args.pipelined and "sweep" not in wl:
         parts = build_problem(de, wl, dev, rank, image_grad, args.pipelined)
         side = [torch.cuda.Stream() for _ in parts]
 
@@ -536,7 +702,7 @@ def main():
         ms = elapsed / args.steps * 1e3
         line = {
             "metric": METRIC,
-            "value": round(value, 4), "unit": "Gpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 4), "unit": "G plane-px/s" if "sweep" in wl else "Gpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "targets_per_gpu": wl["B"], "sources_per_target": wl["S"],
@@ -546,8 +712,10 @@ def main():
                                  (("one C-ABI call per pyramid level (ds_loss_step_fwdbwd); " +
                                    ("finest level on the main stream, the others forked onto side streams and joined inside every step"
                                     if fork_levels else "all levels on one stream"))
-                                  if wl["scales"] > 1 else "whole batch on one stream, one C-ABI call per step (" +
-                                  ("ds_loss_step_fwd: forward only" if wl.get("fwd_only") else "ds_loss_step_fwdbwd") + ")"),
+                                  if wl["scales"] > 1 else "whole batch on one stream, " +
+                                  ("three C-ABI calls per step (ds_resize_bilinear, ds_plane_sweep_depth_batch, ds_resize_bicubic)"
+                                   if "sweep" in wl else "one C-ABI call per step (" +
+                                   ("ds_loss_step_fwd: forward only" if wl.get("fwd_only") else "ds_loss_step_fwdbwd") + ")")),
                        "parallelism": f"batch-sharded x{world}, no collective", "spin_up_s": args.spin_up},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(hbm_frac, 4), "traffic": traffic,
@@ -563,12 +731,25 @@ def main():
             # warped and g_warped round trips between them)
             "kernel_sum_alg_GBps": round(kernel_sum_bytes / (ms * 1e-3) / 1e9, 1),
         }
+        if "sweep" in wl:
+            line["config"].update(planes=wl["sweep"]["D"], cost_height=wl["sweep"]["h"], cost_width=wl["sweep"]["w"])
+        if no_spin is not None:
+            # the same W warm-up + K timed steps BEFORE the spin-up: what a fresh process reads with the device still in
+            # its idle power state (the effect of config.spin_up_s on `value`, in the record)
+            line["value_no_spin_up"] = round(world * warped_px_rank * args.steps / no_spin / 1e9, 4)
+            line["ms_per_step_no_spin_up"] = round(no_spin / args.steps * 1e3, 5)
+        if group is not None:
+            line["process_group"] = group
         if levels_one_stream is not None:
             line["levels_on_one_stream"] = levels_one_stream
         if pipelined is not None:
             line["pipelined_unjoined"] = pipelined
         if cold is not None:
             line["cold_cache"] = cold
+        if world == 1 and not args.no_also and args.workload == "b12_s2_192x640_fwdbwd":
+            del scales, sc0, step, step_one_stream
+            torch.cuda.empty_cache()
+            line["also"] = {name: quick_line(de, name, dev, main_stream) for name in ALSO}
         if not args.no_cpu and world == 1:  # the CPU leg is timed at N=1 only
             line["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(line), flush=True)

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 
 #define DS_HIDDEN __attribute__((visibility("hidden")))
 
@@ -91,14 +92,19 @@ DS_HIDDEN size_t smooth_fb_partials_count(int B, int S, int H, int W);
 DS_HIDDEN int smooth_fb_partials(const float* depths, const float* targets, float scale, int B, int S, int H, int W,
                                  float* g_depths, float* partials, int* n_partials, hipStream_t stream);
 
-// compute units of the current device; cached (the devices of one node are alike), 256 if the query fails
+// Compute units of the device that was current at the first call; cached for the process (std::atomic: concurrent first
+// calls from two host threads may both query, both store the same value), 256 if the query fails.  Every launch geometry
+// and workspace size derives from this one number, so all devices a process drives are assumed to be the same model
+// (one node's MI355Xs are; INTEGRATION.md says so).  Results never depend on it, only how the work is cut.
 inline int cu_count() {
-    static int n = 0;
+    static std::atomic<int> cached{0};
+    int n = cached.load(std::memory_order_relaxed);
     if (n == 0) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
+        cached.store(cus, std::memory_order_relaxed);
         n = cus;
     }
     return n;

@@ -153,9 +153,12 @@ int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, co
                         float* g_pose, float* g_src, void* workspace, size_t workspace_bytes, void* stream) {
     if (B <= 0 || S <= 0 || (long long)B * S > 65535 || H < 2 || W < 2) return DS_ERR_INVALID_ARG;
     if (!K || !Kinv || !pose || !depth || !src || !target || !warped || !out_loss || !idt_loss || !aux || !sums ||
-        !g_warped || !g_depth || !g_pose)
+        !g_depth || !g_pose)
         return DS_ERR_INVALID_ARG;
     if (S > DS_MAX_SOURCES) return DS_ERR_UNSUPPORTED;
+    // d loss / d warped only crosses memory where the loss and the warp's autograd are separate kernels
+    const bool one_kernel_backward = ds::fused_loss_fbw_supported(S) && !g_src;
+    if (!g_warped && !one_kernel_backward) return DS_ERR_INVALID_ARG;
     if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ds_loss_step_fwdbwd_workspace_bytes(B, S, H, W))
         return DS_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -176,7 +179,7 @@ int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, co
         rc = ds::fused_loss_fb_partials(warped, target, idt_loss, g_sums, B, S, H, W, out_loss, aux, g_warped, ws_loss, n_loss,
                                         &wpi, st);
         if (rc != DS_OK) return rc;
-    } else if (ds::fused_loss_fbw_supported(S) && !g_src) {
+    } else if (one_kernel_backward) {
         // S <= 3 (S = 3, the reference's SEQ_LEN - 1, at 168 VGPRs = three waves per SIMD: still 9-13 % faster than the unfused
         // backward, profiles/r02_kb4).  The warp and the identity map (un-warped sources against the target: nothing of it
         // depends on depth or pose) share one launch; then the forward and the backward of the warped groups in ONE kernel:

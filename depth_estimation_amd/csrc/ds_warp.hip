@@ -701,12 +701,9 @@ int ds::warp_bwd_partials(const float* K, const float* Kinv, const float* pose, 
         return DS_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < ds_warp_bwd_workspace_bytes(N, H, W)) return DS_ERR_WORKSPACE;
     const WarpGeom G = warp_geom(Hs, Ws, H, W);
-    // small launches (fewer workgroups than would give every SIMD two waves) take the short tiles
-    int cus = 256, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        cus = 256;
-    const bool small = (long long)warp_tiles(H, W, kBwdRows) * N < 2ll * cus;
+    // small launches (fewer workgroups than would give every SIMD two waves) take the short tiles; only the 3-channel
+    // kernels are instantiated for them (the generic-C kernel keeps kBwdRows, and its grid with it)
+    const bool small = C == 3 && (long long)warp_tiles(H, W, kBwdRows) * N < 2ll * ds::cu_count();
     const int nblk = warp_tiles(H, W, small ? kBwdRowsSmall : kBwdRows);
     dim3 g(nblk, N), b(kThreads);
     float* partials = (float*)workspace;

@@ -101,10 +101,16 @@ class GradBuckets:
 
     # ---- overlapped form: all-reduce every bucket as soon as backward has produced its last gradient ----------------
     def attach(self, group: Optional[dist.ProcessGroup] = None) -> None:
-        """Register one post-accumulate hook per parameter.  During backward, the bucket whose last gradient has just been
+        """Register one post-accumulate hook per parameter.  During backward, a bucket whose last gradient has just been
         accumulated is packed and its all-reduce launched asynchronously (RCCL runs it on its own stream), so the
         collectives of early buckets overlap with the rest of backward.  Call begin() before every backward and
-        finish() after it."""
+        finish() after it.
+
+        Every rank must issue the collectives in the same order, whatever order its gradients arrive in (and whether a
+        parameter receives one at all: a branch not taken on one rank, an unused network): the launch order is FIXED,
+        last bucket first -- backward reaches the parameters roughly in reverse order of their use, so the last bucket
+        fills first -- and bucket i is launched only once every bucket after it has been.  finish() drains what is left
+        in that same order."""
         if self._hooks:
             return
         self._group = group
@@ -123,6 +129,8 @@ class GradBuckets:
     def begin(self) -> None:
         self._pending = [len(b) for b in self.buckets]
         self._handles = [None] * len(self.buckets)
+        self._cursor = len(self.buckets) - 1          # next bucket to launch (descending)
+        self._active = True
 
     def _launch(self, bi: int) -> None:
         flat, off = self._flat[bi], 0
@@ -139,16 +147,23 @@ class GradBuckets:
             self._handles[bi] = False
 
     def _grad_ready(self, bi: int) -> None:
+        if not getattr(self, "_active", False):
+            return      # a backward outside begin()/finish(): gradients stay local (finish() without begin() raises)
         self._pending[bi] -= 1
-        if self._pending[bi] == 0:
-            self._launch(bi)
+        while self._cursor >= 0 and self._pending[self._cursor] <= 0:
+            self._launch(self._cursor)
+            self._cursor -= 1
 
     def finish(self) -> None:
-        """Launch the buckets backward never completed (parameters without a gradient this step), wait for every
-        collective and write the reduced gradients back into p.grad."""
-        for bi in range(len(self.buckets)):
-            if self._handles[bi] is None:
-                self._launch(bi)
+        """Launch the buckets backward never completed (parameters without a gradient this step) in the fixed order,
+        wait for every collective and write the reduced gradients back into p.grad."""
+        if not getattr(self, "_active", False):
+            raise RuntimeError("GradBuckets.finish() without begin(): call begin() before backward so that the hooks count "
+                               "this step's gradients")
+        while self._cursor >= 0:
+            self._launch(self._cursor)
+            self._cursor -= 1
+        self._active = False
         for h in self._handles:
             if h:
                 h.wait()

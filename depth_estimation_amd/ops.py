@@ -429,7 +429,9 @@ class _TrainStepEager(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         nb = lib.ds_train_step_fwdbwd_workspace_bytes(b, s, h, w)
         wsb = L.workspace.get(nb, dev)
-        warped, gw = torch.empty(b, s, 3, h, w, **f32), torch.empty(b, s, 3, h, w, **f32)
+        warped = torch.empty(b, s, 3, h, w, **f32)
+        # d loss / d warped stays inside the kernel for S <= 3; only the S = 4 path needs the (B,S,3,H,W) scratch
+        gw = torch.empty(b, s, 3, h, w, **f32) if s > 3 else None
         out, idt = torch.empty(b, h, w, **f32), torch.empty(b, h, w, **f32)
         aux = torch.empty(b, h, w, dtype=torch.uint8, device=dev)
         sums, reg, total = torch.empty(b, 2, **f32), torch.empty(1, **f32), torch.empty((), **f32)
@@ -437,7 +439,7 @@ class _TrainStepEager(torch.autograd.Function):
         L.check(lib.ds_train_step_fwdbwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
                                          target.data_ptr(), smooth_scale, b, s, h, w, warped.data_ptr(), out.data_ptr(),
                                          idt.data_ptr(), aux.data_ptr(), sums.data_ptr(), reg.data_ptr(), total.data_ptr(),
-                                         gw.data_ptr(), gd.data_ptr(), gp.data_ptr(), wsb.data_ptr(), nb, st),
+                                         L.ptr(gw), gd.data_ptr(), gp.data_ptr(), wsb.data_ptr(), nb, st),
                 "ds_train_step_fwdbwd")
         ctx.save_for_backward(gd, gp)
         ctx.mark_non_differentiable(sums, reg, warped, out, idt, aux)

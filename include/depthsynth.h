@@ -185,8 +185,9 @@ int ds_loss_step_bwd(const float* K, const float* Kinv, const float* pose, const
  * sums[b][0], so the gradients can be formed before the caller's backward runs: g_sums (B) = d(loss)/d(sums[b][0]), or
  * NULL for a unit upstream gradient -- what loss.backward() passes for the reference's summed loss (train.py:88,103); a
  * caller with another upstream factor scales g_depth and g_pose by it.  Outputs as in the four calls it replaces;
- * g_warped (B,S,3,H,W) is scratch (for S <= 3 without g_src the gradient w.r.t. the warped images passes from the loss kernel's
- * waves to the warp's autograd inside one kernel and the buffer is left untouched).  g_src (B,S,3,H,W), optional (NULL
+ * g_warped (B,S,3,H,W) is scratch; for S <= 3 without g_src the gradient w.r.t. the warped images passes from the loss
+ * kernel's waves to the warp's autograd inside one kernel, the buffer is left untouched and may be NULL (with g_src, or
+ * S = 4, NULL is DS_ERR_INVALID_ARG).  g_src (B,S,3,H,W), optional (NULL
  * to skip): the gradient w.r.t. the source images through the warp (cleared and accumulated here; float atomics, as in
  * ds_warp_bwd).  workspace 16-byte aligned, sized by ds_loss_step_fwdbwd_workspace_bytes. */
 size_t ds_loss_step_fwdbwd_workspace_bytes(int B, int S, int H, int W);
@@ -200,7 +201,8 @@ int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, co
  * (metrics.regularization_term, metrics.py:75-97) with its gradient accumulated onto g_depth -- forward value and
  * gradient from one kernel -- and a last launch that forms reg (1) = regularization_term and total (1) = sum_b sums[b][0]
  * + smooth_scale * reg.  g_depth, g_pose = d total / d depth, d total / d pose; a caller with another upstream factor
- * scales them.  Everything else as ds_loss_step_fwdbwd; workspace from ds_train_step_fwdbwd_workspace_bytes. */
+ * scales them.  Everything else as ds_loss_step_fwdbwd (g_warped may be NULL for S <= 3); workspace from
+ * ds_train_step_fwdbwd_workspace_bytes. */
 size_t ds_train_step_fwdbwd_workspace_bytes(int B, int S, int H, int W);
 int ds_train_step_fwdbwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
                          const float* target, float smooth_scale, int B, int S, int H, int W, float* warped,

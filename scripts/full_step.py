@@ -162,30 +162,64 @@ def hip_path(de, H, W, device):
         loss=lambda src, tgt, depth, pose: de.fused.train_step_loss(src, tgt, depth, pose, K, Kinv, eager_grads=True)["total"])
 
 
-def main(args, rank, local_rank, world):
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py --workload full_step needs a GPU (the product path has no CPU fallback)")
+def torch_stand_in_path():
+    """Differentiable torch stand-ins for the three hot-path functions, shapes as the HIP ones.  NOT the product and not
+    its arithmetic: they exist so that the launcher's --dry run and the CPU tests (gloo, no GPU) can drive this harness --
+    networks, buckets, clipping, Adam -- end to end.  The product path is hip_path() and has no CPU form."""
+    def construct_pose_batch(vec):
+        n = vec.shape[0]
+        eye = torch.eye(3, device=vec.device).expand(n, 3, 3)
+        return torch.cat([eye + 0.1 * vec[:, :3, None] * vec[:, None, :3], vec[:, 3:, None]], dim=2)
+
+    def candidate_depths(src, target, pose):
+        return 0.1 + 0.8 * (src.mean(2, keepdim=True) - target[:, None].mean(2, keepdim=True)).abs()
+
+    def loss(src, target, depth, pose):
+        photo = ((src - target[:, None]).abs().mean(2, keepdim=True) * depth / 80.0).mean(dim=(1, 2, 3, 4))
+        return photo.sum() + 0.01 * pose.pow(2).mean(dim=(1, 2, 3)).sum()   # summed over the samples (train.py:88)
+
+    return SimpleNamespace(construct_pose_batch=construct_pose_batch, candidate_depths=candidate_depths, loss=loss)
+
+
+def main(args, rank, local_rank, world, dry=False):
+    """dry: the same harness on the CPU over gloo -- launcher, rendezvous, bucketed all-reduce from the backward hooks,
+    clipping, Adam -- with torch stand-ins for the hot path, tiny networks and images; no kernels, `value` 0."""
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    import depth_estimation_amd as de
-    from depth_estimation_amd.dist import GradBuckets
-    B, S, H, W = 2, 3, 192, 640                                                  # constants.py:6-7 (BATCH_SIZE, SEQ_LEN - 1)
-    nets = build_networks(dev)
+    if dry:
+        dev = torch.device("cpu")
+        torch.set_num_threads(1)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        from depth_estimation_amd.dist import GradBuckets
+        B, S, H, W = 1, 2, 16, 24
+        counts, bucket_bytes = dict(pose=40_000, decoder=3_001, convgru=777), 16 << 10
+        path = torch_stand_in_path()
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py --workload full_step needs a GPU (the product path has no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        import depth_estimation_amd as de
+        from depth_estimation_amd.dist import GradBuckets
+        B, S, H, W = 2, 3, 192, 640                                              # constants.py:6-7 (BATCH_SIZE, SEQ_LEN - 1)
+        counts, bucket_bytes = None, 25 << 20
+        path = hip_path(de, H, W, dev)
+    nets = build_networks(dev, counts)
     params = trainable(nets)
     n_params = sum(p.numel() for p in params)
     opt = torch.optim.Adam(params)                                               # train.py:140
-    buckets = GradBuckets(params, bucket_bytes=25 << 20, average=False)
+    buckets = GradBuckets(params, bucket_bytes=bucket_bytes, average=False)
     buckets.attach()
-    path = hip_path(de, H, W, dev)
     g = torch.Generator().manual_seed(100 + rank)
     imgs = torch.rand(B, S + 1, 3, H, W, generator=g).to(dev)
 
     def barrier():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
@@ -203,7 +237,16 @@ def main(args, rank, local_rank, world):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # the same steps without the collective (what the all-reduce adds when overlapped), and the collective alone
+    # replicas must still hold the same weights after the steps (same initial weights, summed gradients, same Adam)
+    digest = torch.stack([p.detach().double().sum() for p in params]).sum().reshape(1).to(dev)
+    spread = 0.0
+    if world > 1:
+        lo, hi = digest.clone(), digest.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        spread = float((hi - lo).item())
+    # the same steps without the collective (what the all-reduce adds when overlapped; the replicas drift apart from here
+    # on, which is why the spread above is taken first), and the collective alone
     barrier()
     t0 = time.perf_counter()
     run(args.steps, None)
@@ -217,21 +260,33 @@ def main(args, rank, local_rank, world):
             buckets.all_reduce()
         barrier()
         comm_ms = (time.perf_counter() - t0) / args.steps * 1e3
+    # what the process group itself saw: a SUM of ones over the ranks must read N
+    ranks_summed = 1
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones)
+        ranks_summed = int(ones.item())
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         line = {
             "metric": "warped px/s (Gpix/s) fwd+bwd reproj loss @192x640, % HBM roofline, 1-8 GPU",
-            "value": round(world * B * S * H * W * args.steps / elapsed / 1e9, 5), "unit": "Gpix/s", "n_gpus": world,
+            "value": 0.0 if dry else round(world * B * S * H * W * args.steps / elapsed / 1e9, 5), "unit": "Gpix/s",
+            "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "full_step", "samples_per_gpu": B, "sources_per_target": S, "height": H, "width": W,
                        "networks": "stand-ins with the reference's trainable parameter counts", "params": n_params,
                        "parallelism": f"batch-sharded x{world}, gradient all-reduce (RCCL), SUM over ranks"},
             "samples_per_s": round(world * B * args.steps / elapsed, 2),
-            "grad_bytes_all_reduced": buckets.nbytes(), "buckets": len(buckets.buckets), "bucket_bytes": 25 << 20,
+            "world_size": dist.get_world_size() if world > 1 else 1, "ranks_summed": ranks_summed,
+            "backend": dist.get_backend() if world > 1 else None, "replica_weight_spread": spread,
+            "grad_bytes_all_reduced": buckets.nbytes(), "buckets": len(buckets.buckets), "bucket_bytes": bucket_bytes,
             "comm_ms": round(comm_ms, 4), "comm_exposed_ms": round(ms - no_comm / args.steps * 1e3, 4),
             "ms_per_step_without_collective": round(no_comm / args.steps * 1e3, 4),
         }
+        if dry:
+            line["dry"] = True
+            line["config"]["networks"] = "tiny stand-ins; torch stand-ins for the hot path (launcher / collective check only)"
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -36,3 +36,17 @@ def test_single_rank_needs_no_launcher():
 def test_world_size_mismatch_is_an_error():
     p = _run("--gpus", "2", env_extra={"WORLD_SIZE": "1", "RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
+
+
+def test_full_step_harness_two_ranks_dry():
+    """bench.py --gpus 2 --dry --workload full_step: the config-5 harness through self_launch over gloo -- the line proves
+    the process group saw both ranks (world_size, a SUM of ones), carries comm_ms, and the replicas' weights agree."""
+    p = _run("--gpus", "2", "--workload", "full_step")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["dry"] is True and line["n_gpus"] == 2 and line["world_size"] == 2 and line["ranks_summed"] == 2
+    assert line["backend"] == "gloo" and line["config"]["workload"] == "full_step"
+    assert line["comm_ms"] > 0 and line["buckets"] >= 3 and line["grad_bytes_all_reduced"] == 4 * (40_000 + 3_001 + 777)
+    assert line["replica_weight_spread"] == 0.0

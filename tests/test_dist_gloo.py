@@ -66,6 +66,64 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_uneven(rank, world, port, q):
+    """Overlapped buckets where the ranks' gradients arrive in different orders and rank 1 leaves a whole bucket without
+    a gradient (an unused branch): the collectives must still pair bucket with bucket."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        D = _import_dist()
+        # four parameters of EQUAL size, one per bucket: mispaired collectives would not hang, they would sum wrong buffers
+        params = [torch.nn.Parameter(torch.full((8,), float(i + 1))) for i in range(4)]
+        gb = D.GradBuckets(params, bucket_bytes=32, average=False)
+        assert len(gb.buckets) == 4
+        gb.attach()
+        # a backward without begin() leaves the gradients local and launches nothing
+        (params[0] * 1.0).sum().backward()
+        assert float(params[0].grad[0]) == 1.0
+        params[0].grad = None
+        try:
+            gb.finish()
+            raised = False
+        except RuntimeError:
+            raised = True
+        out = []
+        for step in range(2):
+            for p in params:
+                p.grad = None
+            gb.begin()
+            if rank == 0:       # uses the parameters in the order 0,1,2,3: backward reaches 3 first
+                loss = sum((i + 1) * (p * (10.0 + step)).sum() for i, p in enumerate(params))
+            else:               # the other way round, and parameter 1 not at all
+                loss = sum((i + 1) * (params[i] * (20.0 + step)).sum() for i in (3, 2, 0))
+            loss.backward()
+            gb.finish()
+            out.append([float(p.grad[0]) for p in params])
+        q.put((rank, raised, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_overlapped_buckets_fixed_order():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, raised, out in res:
+        assert raised                                  # finish() without begin() is a clear error
+        for step, got in enumerate(out):
+            # SUM over ranks of (i+1) * factor; rank 1 contributes nothing to parameter 1
+            want = [(i + 1) * ((10.0 + step) + (0.0 if i == 1 else 20.0 + step)) for i in range(4)]
+            assert got == want, (rank, step, got, want)
+
+
 def test_shard_range_partitions_every_batch():
     D = _import_dist()
     for B in (0, 1, 5, 12, 64):

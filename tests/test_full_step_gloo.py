@@ -7,7 +7,6 @@ import importlib.util
 import os
 import socket
 import sys
-from types import SimpleNamespace
 
 import torch
 import torch.distributed as dist
@@ -26,20 +25,8 @@ def _load(name, rel):
 
 
 def _torch_path():
-    """differentiable torch stand-ins for the three hot-path functions (shapes as the HIP ones)"""
-    def construct_pose_batch(vec):
-        n = vec.shape[0]
-        eye = torch.eye(3).expand(n, 3, 3)
-        return torch.cat([eye + 0.1 * vec[:, :3, None] * vec[:, None, :3], vec[:, 3:, None]], dim=2)
-
-    def candidate_depths(src, target, pose):
-        return 0.1 + 0.8 * (src.mean(2, keepdim=True) - target[:, None].mean(2, keepdim=True)).abs()
-
-    def loss(src, target, depth, pose):
-        photo = ((src - target[:, None]).abs().mean(2, keepdim=True) * depth / 80.0).mean(dim=(1, 2, 3, 4))
-        return photo.sum() + 0.01 * pose.pow(2).mean(dim=(1, 2, 3)).sum()   # summed over the samples (train.py:88)
-
-    return SimpleNamespace(construct_pose_batch=construct_pose_batch, candidate_depths=candidate_depths, loss=loss)
+    """differentiable torch stand-ins for the three hot-path functions (scripts/full_step.torch_stand_in_path)"""
+    return _load("full_step", "scripts/full_step.py").torch_stand_in_path()
 
 
 def _setup(fs, D, average=False):

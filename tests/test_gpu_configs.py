@@ -47,7 +47,7 @@ def sid_depths(max_depth=80.0, n=80):
 # ------------------------------------------------------------------------------------------------------------------------
 # config 5
 # ------------------------------------------------------------------------------------------------------------------------
-def test_config5_full_step_against_the_per_sample_sequence(de):
+def test_config5_full_step_against_the_per_sample_sequence(de, oracle):
     """scripts/full_step.train_step (B=2, S=3, 192x640 = constants.py's BATCH_SIZE, SEQ_LEN-1, HEIGHT, WIDTH; stand-in
     networks with tiny filler counts) with hip_path: the candidate depths it feeds the networks, the loss, d loss / d depth
     and d loss / d pose VECTORS against the reference's per-sample loop (train.py:39-89) written with the drop-in
@@ -59,8 +59,13 @@ def test_config5_full_step_against_the_per_sample_sequence(de):
     B, S, H, W = 2, 3, 192, 640
     counts = dict(pose=20_000, decoder=1_000, convgru=500)
     nets = fs.build_networks(torch.device(DEV), counts, seed=3)
+    with torch.no_grad():
+        # a freshly initialised stand-in PoseNet answers ~1e-3 for every component; with a translation that small the depth
+        # gradient is the O(t) remainder of O(depth) terms that cancel and no two fp32 evaluations agree to 1e-4 of it.
+        # Bias it to the motion of the golden real-frame case (KITTI-like: 0.3 m sideways, 0.5 m forward, small rotation).
+        nets.pose.fc.bias.copy_(torch.tensor([0.6, -0.9, 0.3, 30.0, -5.0, 50.0]))
     params = fs.trainable(nets)
-    before = [p.detach().clone() for p in params]
+    before =[p.detach().clone() for p in params]
     opt = torch.optim.Adam(params)
     path = fs.hip_path(de, H, W, torch.device(DEV))
     seen = {}
@@ -114,9 +119,24 @@ def test_config5_full_step_against_the_per_sample_sequence(de):
         s = met.reprojection_loss(src_imgs, target_imgs)                                            # :85
         total = total + torch.mean(torch.mean(o / torch.exp(s + 1e-6), dim=(2, 3))) + 0.02 * reg    # :88-89
     total.backward()
-    assert abs(float(got) - float(total)) < 1e-5 * max(1.0, abs(float(total)))
-    assert rel_to_max(N(depth.grad), N(depth2.grad)) < 1e-4
-    assert rel_to_max(N(vec.grad), N(vec2.grad)) < 1e-4
+    assert abs(float(got) - float(total.detach())) < 1e-5 * max(1.0, abs(float(total.detach())))
+    # two fp32 evaluations in different orders, each allowed 1e-4 of the largest gradient against the reference: 2e-4
+    # between them (1.6e-4 observed on the depth gradient of this near-constant 40 m depth map) ...
+    assert rel_to_max(N(depth.grad), N(depth2.grad)) < 2e-4
+    assert rel_to_max(N(vec.grad), N(vec2.grad)) < 2e-4
+    # ... and the fused step's depth gradient against the oracle's double-precision adjoint at the bar itself
+    Kn, Kin = N(K), N(Kinv)
+    pose_np = N(path.construct_pose_batch(vec.detach())).reshape(B, S, 3, 4)
+    dnp, inp = N(depth), N(imgs)
+    for b in range(B):
+        src_b, tgt_b = inp[b, :-1], inp[b, -1]
+        ow = np.stack([oracle.warp(Kn, Kin, pose_np[b, s], dnp[b, s, 0], src_b[s], H, W) for s in range(S)])
+        la = oracle.loss_assembly(ow, src_b, tgt_b)
+        ogw = oracle.loss_assembly_bwd(ow, tgt_b, la["idt_loss"], la["argmin"])
+        ogd = np.stack([oracle.warp_bwd(Kn, Kin, pose_np[b, s], dnp[b, s, 0], src_b[s], ogw[s], H, W, False)[0] for s in range(S)])
+        _, greg = oracle.regularization_term(dnp[b] / np.float32(fs.MAX_DEPTH), np.stack([tgt_b] * S), want_grad=True)
+        want = ogd[:, None] + 0.02 * greg / fs.MAX_DEPTH                       # train.py:89
+        assert rel_to_max(N(depth.grad)[b], want) < 1e-4, b
     # train.py:102-109
     for m in (nets.pose, nets.decoder, nets.convgru):
         gs = [p.grad for p in m.parameters()]

@@ -153,6 +153,26 @@ def test_warp_backward(de, oracle, name):
     assert rel_to_max(N(pose2.grad), N(pose.grad)) < 1e-5
 
 
+@pytest.mark.parametrize("N_,C,H,W", [(1, 2, 20, 70), (2, 1, 37, 131), (3, 4, 9, 64)])
+def test_warp_backward_other_channel_counts(de, oracle, N_, C, H, W):
+    """ds_warp_bwd for C != 3 (the generic kernel; launches small enough that the 3-channel kernels would switch to their
+    short tiles): depth, pose and image gradients against oracle.warp_bwd, 1e-4 of the largest."""
+    rng = np.random.default_rng(C * 100 + H)
+    K, Kinv = [a.numpy() for a in de.fused.intrinsics(W, H)]
+    src = rng.random((N_, C, H, W), dtype=np.float32)
+    depth = (1 + 79 * rng.random((N_, H, W), dtype=np.float32)).astype(np.float32)
+    g_warped = rng.standard_normal((N_, C, H, W)).astype(np.float32)
+    pm = oracle.pose_from_vec((0.01 * rng.standard_normal((N_, 6))).astype(np.float32))
+    dep, pose, sr = T(depth).requires_grad_(True), T(pm).requires_grad_(True), T(src).requires_grad_(True)
+    w = de.ops.warp(T(K), T(Kinv), pose, dep, sr)
+    assert np.array_equal(N(w), np.stack([oracle.warp(K, Kinv, pm[n], depth[n], src[n], H, W) for n in range(N_)]))
+    w.backward(T(g_warped))
+    gd, gp, gs = zip(*[oracle.warp_bwd(K, Kinv, pm[n], depth[n], src[n], g_warped[n], H, W) for n in range(N_)])
+    assert rel_to_max(N(dep.grad), np.stack(gd)) < 1e-4
+    assert rel_to_max(N(pose.grad), np.stack(gp)) < 1e-4
+    assert rel_to_max(N(sr.grad), np.stack(gs)) < 1e-4
+
+
 @pytest.mark.parametrize("motion", ["subpixel", "disparity", "far"])
 def test_image_gradient_any_motion(de, oracle, motion):
     """The image-gradient scatter of ds_warp_bwd collects a wave's taps in an LDS tile around its first row and sends the
@@ -670,6 +690,19 @@ def test_train_step_in_one_call(de, oracle, B, S, H, W):
     assert abs(float(reg) - float(reg2)) <= 1e-6 * abs(float(reg2))
     want = float(b_["sums"][:, 0].sum()) + scale * float(reg2)
     assert abs(float(total) - want) <= 1e-6 * abs(want)
+    # without the d loss / d warped scratch: fine where it never crosses memory (S <= 3), an argument error otherwise
+    c = bufs()
+    rc = lib.ds_train_step_fwdbwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
+                                  tgt.data_ptr(), scale, B, S, H, W, c["warped"].data_ptr(), c["out"].data_ptr(),
+                                  c["idt"].data_ptr(), c["aux"].data_ptr(), c["sums"].data_ptr(), reg.data_ptr(),
+                                  total.data_ptr(), 0, c["gd"].data_ptr(), c["gp"].data_ptr(), ws.data_ptr(), n, st)
+    torch.cuda.synchronize()
+    if S <= 3:
+        assert rc == 0
+        for k in ("warped", "out", "idt", "aux", "sums", "gp", "gd"):
+            assert torch.equal(a[k], c[k]), k
+    else:
+        assert rc == -1
     # regularization_term of the reference (oracle): depth maps (N,1,H,W) against their targets stacked S times
     tg = tgt[:, None].expand(B, S, 3, H, W).reshape(N_, 3, H, W)
     ref = oracle.regularization_term(N(depth.reshape(N_, 1, H, W)), N(tg))
