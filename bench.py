@@ -91,9 +91,10 @@ class Scale:
         self.g_warped = torch.empty(B, S, 3, H, W, **f)
         self.g_depth = torch.empty(B, S, H, W, **f)
         self.g_pose = torch.empty(B, S, 3, 4, **f)
-        self.g_src = torch.zeros(B, S, 3, H, W, **f) if image_grad else None
+        self.g_src = torch.empty(B, S, 3, H, W, **f) if image_grad else None   # written whole by the call (no clearing)
         self.ws_loss_n = self.lib.ds_fused_loss_workspace_bytes(B, H, W)
-        self.ws_warp_n = self.lib.ds_warp_bwd_workspace_bytes(self.N, H, W)
+        self.ws_warp_n = (self.lib.ds_warp_bwd_image_workspace_bytes(self.N, 3, H, W, H, W) if image_grad
+                          else self.lib.ds_warp_bwd_workspace_bytes(self.N, H, W))
         self.ws_loss = torch.empty(self.ws_loss_n, dtype=torch.uint8, device=dev)
         self.ws_warp = torch.empty(self.ws_warp_n, dtype=torch.uint8, device=dev)
         p = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
@@ -179,7 +180,8 @@ class Scale:
         self.names = tuple(self.calls) + (("metrics",) if metrics else ())
         # the step as ONE call (forward + backward launches and a single merged finalize; with the image gradient also the
         # clearing of g_src)
-        self.ws_step_n = self.lib.ds_loss_step_fwdbwd_workspace_bytes(B, S, H, W)
+        self.ws_step_n = (self.lib.ds_loss_step_fwdbwd_image_workspace_bytes(B, S, H, W) if image_grad
+                          else self.lib.ds_loss_step_fwdbwd_workspace_bytes(B, S, H, W))
         self.ws_step = torch.empty(self.ws_step_n, dtype=torch.uint8, device=dev)
         self.one_call = lambda st: lib.ds_loss_step_fwdbwd(
             p(self.K), p(self.Kinv), p(self.pose), p(self.depth), p(self.src), p(self.tgt), 0, B, S, H, W, p(self.warped),
@@ -205,8 +207,6 @@ class Scale:
                 if rc != 0:
                     self.L.check(rc, "metrics")
             return
-        if self.g_src is not None:
-            self.g_src.zero_()
         for name in self.names:
             rc = self.calls[name](st)
             if rc != 0:

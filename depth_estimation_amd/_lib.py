@@ -31,6 +31,7 @@ _SIGNATURES = {
     "ds_grid_sample_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp]),
     "ds_warp_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp]),
     "ds_warp_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ds_warp_bwd_image_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "ds_warp_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _sz, _fp]),
     "ds_synthesize_from_depths": (_i, [_fp, _fp, _fp, C.POINTER(C.c_double), _i, _fp, _i, _i, _i, _i, _i, _fp, _fp]),
     "ds_depth_from_costs": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _fp]),
@@ -58,6 +59,7 @@ _SIGNATURES = {
     "ds_loss_step_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "ds_loss_step_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _sz, _fp]),
     "ds_loss_step_fwdbwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ds_loss_step_fwdbwd_image_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ds_loss_step_fwdbwd": (_i, [_fp] * 7 + [_i] * 4 + [_fp] * 9 + [_fp, _sz, _fp]),
     "ds_train_step_fwdbwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ds_train_step_fwdbwd": (_i, [_fp] * 6 + [_f32] + [_i] * 4 + [_fp] * 10 + [_fp, _sz, _fp]),

@@ -147,6 +147,13 @@ size_t ds_loss_step_fwdbwd_workspace_bytes(int B, int S, int H, int W) {
     return a > b ? a : b;
 }
 
+size_t ds_loss_step_fwdbwd_image_workspace_bytes(int B, int S, int H, int W) {
+    if (B <= 0 || S <= 0 || H < 2 || W < 2) return 0;
+    // with g_src the loss and the warp's autograd are separate kernels: loss partials, then the warp backward's workspace
+    // with the staging of the image gradient
+    return loss_partials_bytes(B, H, W) + ds_warp_bwd_image_workspace_bytes(B * S, 3, H, W, H, W);
+}
+
 int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
                         const float* target, const float* g_sums, int B, int S, int H, int W, float* warped,
                         float* out_loss, float* idt_loss, uint8_t* aux, float* sums, float* g_warped, float* g_depth,
@@ -159,18 +166,15 @@ int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, co
     // d loss / d warped only crosses memory where the loss and the warp's autograd are separate kernels
     const bool one_kernel_backward = ds::fused_loss_fbw_supported(S) && !g_src;
     if (!g_warped && !one_kernel_backward) return DS_ERR_INVALID_ARG;
-    if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ds_loss_step_fwdbwd_workspace_bytes(B, S, H, W))
+    if (!workspace || ((uintptr_t)workspace & 15) ||
+        workspace_bytes < (g_src ? ds_loss_step_fwdbwd_image_workspace_bytes(B, S, H, W)
+                                 : ds_loss_step_fwdbwd_workspace_bytes(B, S, H, W)))
         return DS_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const size_t n_loss = loss_partials_bytes(B, H, W);
     void* ws_loss = workspace;
     void* ws_warp = (char*)workspace + n_loss;
     int rc, wpi = 0, nblk = 0;
-    if (g_src) {
-        // the image gradient is a scatter into zeroed memory (float atomics, ds_warp_bwd)
-        hipError_t e = hipMemsetAsync(g_src, 0, (size_t)B * S * 3 * H * W * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
-    }
     if (ds::fused_loss_fb_supported(S) && g_src) {
         // with the image gradient: warp + identity map, fused loss forward+backward (d loss / d warped to memory), then
         // the warp backward kernel that scatters

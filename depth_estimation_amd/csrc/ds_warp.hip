@@ -15,6 +15,14 @@
 
 using namespace ds;
 
+#ifndef DS_IMG_EXP
+#define DS_IMG_EXP 0   // 32: diagnostic build of img_reduce_kernel (WRONG g_src: every wave's first texels carry its lifetime
+                       // in cycles, the point lists and entries it looked at and its hits; read by scripts/img_diag.py)
+#endif
+#ifndef DS_RED_ROWS
+#define DS_RED_ROWS 2
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -179,22 +187,69 @@ constexpr int kBwdRowsSmall = 2;       // for launches too small to fill the chi
 
 // Image-gradient scatter (IMG).  Direct scatter = 4 device-scope float atomics per pixel and channel: 382 us against 31 us
 // for the rest of the backward at B=12, 192x640.  Collecting the taps in an LDS tile first was measured too: the LDS float
-// atomics (~20 cycles per wave instruction) then cost what the global ones did (213 us; scripts/ubench_atomic.hip for the
-// global rates: 324 G lane-operations/s coalesced and aligned).  What is done instead needs neither: for a smooth warp the
-// taps of the 64 pixels of a wave row fall into a window of three source rows x 66 columns that moves down one row per
-// pixel row, so
+// atomics (~20 cycles per wave instruction) then cost what the global ones did (213 us).  What is done instead: for a smooth
+// warp the taps of the 64 pixels of a wave row fall into a window of three source rows x 66 columns that moves down one row
+// per pixel row, so
 //   * lane x owns source column x + cb of the window; the taps of lanes x-1, x, x+1 that fall into that column are
 //     combined in registers (two lane shuffles per value), three running sums per channel (rows r0, r0+1, r0+2);
-//   * when the window moves on, the finished row r0 goes to memory with ONE coalesced atomic per texel and channel
-//     (atomic because the windows of neighbouring waves overlap at their edges); about 1.25 atomics per pixel and
-//     channel instead of 4, all of them full aligned lines;
 //   * a pixel whose taps do not fit the window (a near pixel among far ones: its disparity differs by more than a texel)
 //     is broadcast from its lane and taken over by the two lanes that own its columns if rows and columns are still
-//     inside the window, otherwise that lane scatters it directly with four atomics per channel; if more than a few
-//     lanes of a row misfit (strong minification, source larger than the grid) the whole row is scattered directly.
-//     The result never depends on the path taken.
-// B=12, 192x640, image gradient on: 382 us direct, 213 us LDS tile, 128 us this way with bench.py's random per-pixel
-// depth (about 5 % misfits), 91 us with a smooth depth map; 34 us without the image gradient (scripts/img_grad_bench.py).
+//     inside the window, otherwise it leaves the wave on its own ("point"); if more than a few lanes of a row misfit (strong
+//     minification, source larger than the grid) the whole row leaves as points.  The result never depends on the path.
+//
+// Rounds 1-2 sent finished window rows and points to memory with float atomics (one coalesced atomic per texel and channel
+// for a row, 4 per channel for a point): 2.0 M requests at the memory side per launch, 66 of the kernel's 127 us, and sums
+// whose last bits changed from run to run (the windows of neighbouring waves overlap, border texels collect hundreds of
+// terms in varying order).  Round 3: NO atomics of any kind, nothing to clear.  Everything a wave produces goes with plain
+// stores into staging that is the wave's own ("tile" = the 64 columns x ROWS rows of pixels a wave walks):
+//   * a finished window row ("segment": 66 columns x 3 channels) into the tile's row slot k = source row - rbase, rbase =
+//     two rows above the first row the wave finishes, kSegRows slots; the tile's record keeps rbase, a mask of the filled
+//     slots and each slot's first column.  A row that does not fit (the window jumped backwards or far ahead, or comes to a
+//     slot a second time) leaves as points;
+//   * a point (2 texels x 3 channels of one source row) is appended to the tile's point list, its position from a ballot
+//     prefix inside the wave; the record keeps the count and the row / column range of the list.
+// img_reduce_kernel then forms every texel of g_src exactly once -- one thread per texel column of one source row: it looks
+// through the tile records of its image for segments of its row that cover its columns and for point lists whose ranges
+// include them, and adds what it finds IN A FIXED ORDER (tiles by index, a tile's points in list order), so the sum is
+// bit-identical from run to run; the texel is written with a plain store (g_src needs no clearing).  First version of the
+// round: per-row directories filled through returning integer atomics and a 64-bit fixed-point sum in the reducer -- correct
+// and repeatable, and 4x slower than the float atomics (the atomics' round trips serialise the row loop, the fixed-point
+// conversions cost 128 us): profiles/r03_kb2_image_gradient.txt.
+constexpr int kSegRows = 16;        // row slots per tile (a wave of 8 pixel rows finishes 10 window rows if the warp is smooth)
+constexpr int kSegFloats = 3 * 66;  // one slot: 3 channels x (outer column, 64 owned columns, outer column)
+// A tile's record, structure-of-arrays so that the reducer's lanes read the records of 64 consecutive tiles as consecutive
+// 16-byte words (as an array of 112-byte structs every lane touched a cache line of its own: 47 of the reducer's 85 us):
+//   hdrA[tile] = { rbase: source row of slot 0,  mask: filled slots (bit 31: the point list is not empty),
+//                  cbmin, cbmax: range of cb[] over the filled slots }
+//   hdrB[tile] = { npt: entries of the point list,  prmin, prmax: the rows they span,  - }
+//   cb[tile][kCbStride]: [k] = source column of slot k's first OWNED column (entry 1 of its 66); [16], [17] = the range of
+//                  the points' left columns
+constexpr int kCbStride = kSegRows + 2;
+struct PtEntry {                    // the two texels (col, col+1) of source row `row`; 32 bytes
+    int row, col;
+    float v[3][2];
+};
+struct ImgStage {                   // into the caller's workspace (ds_warp_bwd_image_workspace_bytes)
+    int4* hdrA;                     // [N][nwy][nbx]
+    int4* hdrB;
+    int* cb;                        // [N][nwy][nbx][kCbStride]
+    float* seg;                     // [N][nwy][nbx][kSegRows][kSegFloats]
+    PtEntry* pt;                    // [N][nwy][nbx][pts_per_tile]
+    int nwy;                        // tile rows per image = ceil(H / ROWS)
+    int pts_per_tile;               // worst case: every pixel a point (2 entries) or every finished row misplaced (66 + 2)
+};
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
 struct ImgWindow {
     float a[3][3];   // [channel][window row]
     float e[3][3];   // the same for the window's outer columns x0+cb-1 (held by lane 0) and x63+cb+1 (lane 63)
@@ -212,7 +267,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
                                                             const float* __restrict__ src,
                                                             const float* __restrict__ g_warped, int Cdyn, WarpGeom G,
                                                             float* __restrict__ g_depth, float* __restrict__ g_src,
-                                                            float* __restrict__ partials) {
+                                                            float* __restrict__ partials, ImgStage st) {
     __shared__ float lds[kThreads / 64][12];
     const int n = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -239,27 +294,69 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
 #pragma unroll
     for (int c = 0; c < 3; ++c)
         win.a[c][0] = win.a[c][1] = win.a[c][2] = win.e[c][0] = win.e[c][1] = win.e[c][2] = 0.f;
-    // finished window rows go to memory: one coalesced atomic per texel and channel, one more for the two outer columns
-    auto emit_row = [&](int slot) {
-        const int r = win.r0 + slot, col = x + win.cb;
-        if (r < 0 || r >= G.Hs) return;  // uniform
-        float* q = g_src + (size_t)n * 3 * HsWs + (size_t)r * G.Ws;
-        if (col >= 0 && col < G.Ws) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                if (win.a[c][slot] != 0.0f) atomicAdd(q + (size_t)c * HsWs + col, win.a[c][slot]);
+    // ---- staging of this wave's tile (IMG): see the comment above ImgStage
+    const int wy = by * (kThreads / 64) + wave;
+    const size_t tix = ((size_t)n * st.nwy + wy) * G.nbx + bx;
+    int rbase = 0, npt = 0;          // uniform
+    int cbmin = 0x7fffffff, cbmax = -0x7fffffff - 1;   // uniform
+    unsigned smask = 0;              // uniform; rbase is valid once smask != 0 or a row has been turned away
+    bool have_base = false;
+    int prmin = 0x7fffffff, prmax = -0x7fffffff - 1, pcmin = 0x7fffffff, pcmax = -0x7fffffff - 1;   // per lane
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    // append one point per lane with `has` to the tile's list, in lane order
+    auto push_point = [&](bool has, int row, int pcol, float a0, float a1, float a2, float b0, float b1, float b2) {
+        const unsigned long long m = __ballot(has);
+        if (m == 0) return;   // uniform
+        if (has) {
+            PtEntry* e = st.pt + tix * st.pts_per_tile + npt + __popcll(m & lt_mask);
+            e->row = row;
+            e->col = pcol;
+            e->v[0][0] = a0; e->v[0][1] = b0;
+            e->v[1][0] = a1; e->v[1][1] = b1;
+            e->v[2][0] = a2; e->v[2][1] = b2;
+            prmin = min(prmin, row); prmax = max(prmax, row);
+            pcmin = min(pcmin, pcol); pcmax = max(pcmax, pcol);
         }
-        if (lane == 0 || lane == 63) {
-            const int ecol = col + (lane == 0 ? -1 : 1);  // inside the image whenever the sum is not zero
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                if (win.e[c][slot] != 0.0f) atomicAdd(q + (size_t)c * HsWs + ecol, win.e[c][slot]);
-        }
+        npt += __popcll(m);
     };
-    auto clear_window = [&]() {
+    // the window's row 0 is finished: stage it, then move the window down one row
+    auto emit_shift = [&]() {
+        const int r = win.r0;
+        const bool nz = win.a[0][0] != 0.0f || win.a[1][0] != 0.0f || win.a[2][0] != 0.0f;
+        const bool enz = (lane == 0 || lane == 63) && (win.e[0][0] != 0.0f || win.e[1][0] != 0.0f || win.e[2][0] != 0.0f);
+        if (IMG && r >= 0 && r < G.Hs && __ballot(nz || enz) != 0) {   // uniform
+            if (!have_base) { rbase = r - 2; have_base = true; }
+            const int k = r - rbase;
+            if (k >= 0 && k < kSegRows && !((smask >> k) & 1u)) {
+                float* p = st.seg + (tix * kSegRows + k) * kSegFloats;
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-            win.a[c][0] = win.a[c][1] = win.a[c][2] = win.e[c][0] = win.e[c][1] = win.e[c][2] = 0.f;
+                for (int c = 0; c < 3; ++c) p[c * 66 + 1 + lane] = win.a[c][0];
+                if (lane == 0 || lane == 63) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) p[c * 66 + (lane == 0 ? 0 : 65)] = win.e[c][0];
+                }
+                const int cb0 = bx * 64 + win.cb;
+                if (lane == 0) st.cb[tix * kCbStride + k] = cb0;
+                cbmin = min(cbmin, cb0);
+                cbmax = max(cbmax, cb0);
+                smask |= 1u << k;
+            } else {
+                // no slot for this row: it leaves as points (a lane's own column, then the two outer columns)
+                const int col = x + win.cb;
+                push_point(nz, r, col, win.a[0][0], win.a[1][0], win.a[2][0], 0.f, 0.f, 0.f);
+                push_point(enz, r, col + (lane == 0 ? -1 : 1), win.e[0][0], win.e[1][0], win.e[2][0], 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            win.a[c][0] = win.a[c][1];
+            win.a[c][1] = win.a[c][2];
+            win.a[c][2] = 0.f;
+            win.e[c][0] = win.e[c][1];
+            win.e[c][1] = win.e[c][2];
+            win.e[c][2] = 0.f;
+        }
+        win.r0 += 1;
     };
 #pragma unroll 2
     for (int i = 0; i < ROWS; ++i) {
@@ -301,6 +398,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
             // r0+1.  A few misfits (near pixels among far ones) are scattered directly, lane by lane; more than
             // kMaxMisfits and the window is wrong for this row
             constexpr int kMaxMisfits = 12;
+            constexpr int kMinRunLanes = 4;   // lanes continuing a run of equal taps before the wave sums runs (below)
             auto misfits = [&](int r0_, int cb_) {
                 rel = dx - (cb_ - 1);
                 rr = t.y0 - r0_;
@@ -308,22 +406,18 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
                 return __popcll(__ballot(valid && !lane_ok));
             };
             bool ok = false;
+            int nemit = 0;            // finished window rows to stage before this row's taps are added (uniform)
+            int nr0 = 0, ncb = 0;     // the window after that
             if (win.live) {
                 if (misfits(win.r0 + 1, win.cb) <= kMaxMisfits) {   // the usual case: the window moves down one row
-                    emit_row(0);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        win.a[c][0] = win.a[c][1];
-                        win.a[c][1] = win.a[c][2];
-                        win.a[c][2] = 0.f;
-                        win.e[c][0] = win.e[c][1];
-                        win.e[c][1] = win.e[c][2];
-                        win.e[c][2] = 0.f;
-                    }
-                    win.r0 += 1;
+                    nemit = 1;
+                    nr0 = win.r0 + 1;
+                    ncb = win.cb;
                     ok = true;
-                } else {
-                    ok = misfits(win.r0, win.cb) <= kMaxMisfits;    // or stays
+                } else if (misfits(win.r0, win.cb) <= kMaxMisfits) {   // or stays
+                    nr0 = win.r0;
+                    ncb = win.cb;
+                    ok = true;
                 }
             }
             if (!ok) {  // a new window around the tap of the wave's first pixel (always inside the image)
@@ -336,20 +430,21 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
                     if (m < best) { best = m; br = r0_; bc = cb_; }
                 }
                 if (best <= kMaxMisfits) {
-                    if (win.live) {
-                        emit_row(0);
-                        emit_row(1);
-                        emit_row(2);
-                    }
-                    clear_window();
-                    win.r0 = br;
-                    win.cb = bc;
+                    nemit = win.live ? 3 : 0;
+                    nr0 = br;
+                    ncb = bc;
                     win.live = true;
-                    misfits(br, bc);
                     ok = true;
                 }
             }
-            bool direct = valid && !ok;  // pixels that go to memory with four atomics per channel
+#pragma unroll 1
+            for (int k = 0; k < nemit; ++k) emit_shift();   // the one place finished rows leave from (inlined once)
+            if (ok) {
+                win.r0 = nr0;      // (after three emits the window is empty)
+                win.cb = ncb;
+                misfits(nr0, ncb);
+            }
+            bool direct = valid && !ok;  // pixels that leave as points
             if (ok) {
                 // the pixel's four weights as a 3 (window rows) x 3 (owner columns x-1, x, x+1) stencil
                 const float wat = lane_ok ? t.wa_t : 0.f, wbt = lane_ok ? t.wb_t : 0.f;
@@ -408,18 +503,51 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
                     }
                 }
             }
-            if (direct) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float gc = g[c];
-                    if (gc != 0.0f) {
-                        float* q = g_src + ((size_t)n * 3 + c) * HsWs;
-                        if (t.wa_t != 0.0f) atomicAdd(q + (t.o_top >> 2), gc * t.wa_t);
-                        if (t.wb_t != 0.0f) atomicAdd(q + (t.o_top >> 2) + 1, gc * t.wb_t);
-                        if (t.wa_b != 0.0f) atomicAdd(q + (t.o_bot >> 2), gc * t.wa_b);
-                        if (t.wb_b != 0.0f) atomicAdd(q + (t.o_bot >> 2) + 1, gc * t.wb_b);
-                    }
+            {
+                // points: the top and the bottom texel row of every pixel that did not go through the window
+                const bool any = direct && (g[0] != 0.0f || g[1] != 0.0f || g[2] != 0.0f);
+                // A run of neighbouring lanes on ONE tap (pixels beyond the left or right border all clamp to the border
+                // column; a far plane collapses onto a texel) would reach the reducer as that many entries for one texel,
+                // which one of its threads then adds one after the other (chunk 0 of a forward-moving camera: 640 k cycles
+                // for a wave against a median of 27 k).  Such runs are summed here first, by a segmented scan over the
+                // lanes -- a fixed tree, so still the same bits every run -- and only a run's last lane leaves an entry.
+                // (the three shuffles with every lane active: a lane switched off by a short-circuit reads as 0)
+                const bool prev_any = __shfl_up((int)any, 1, 64) != 0;
+                const int prev_y0 = __shfl_up(t.y0, 1, 64), prev_xl = __shfl_up(t.xl, 1, 64);
+                const bool cont = any && lane > 0 && prev_any && prev_y0 == t.y0 && prev_xl == t.xl;
+                const unsigned long long cm = __ballot(cont);
+                const bool scan = __popcll(cm) >= kMinRunLanes;   // uniform
+                int head = lane;
+                bool last = true;
+                if (scan) {
+                    head = 63 - __builtin_clzll(~cm & (lt_mask | (1ull << lane)));   // first lane of this lane's run
+                    last = lane == 63 || !((cm >> (lane + 1)) & 1ull);
                 }
+                auto row_points = [&](int row, float wa, float wb) {
+                    float v[6];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        v[2 * c] = any ? g[c] * wa : 0.f;
+                        v[2 * c + 1] = any ? g[c] * wb : 0.f;
+                    }
+                    if (scan) {
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const bool take = lane - o >= head;
+#pragma unroll
+                            for (int q = 0; q < 6; ++q) {
+                                const float u = __shfl_up(v[q], o, 64);
+                                v[q] += take ? u : 0.f;
+                            }
+                        }
+                    }
+                    bool nzv = false;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) nzv = nzv || v[q] != 0.0f;
+                    push_point(any && last && nzv, row, t.xl, v[0], v[2], v[4], v[1], v[3], v[5]);
+                };
+                row_points(t.y0, t.wa_t, t.wb_t);
+                row_points(t.y1, t.wa_b, t.wb_b);
             }
         } else if (g_src && x < G.W) {  // generic channel count: float atomics straight to memory
             Samp s;
@@ -451,12 +579,336 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
         }
         if (x < G.W) buf_store_f32(gd, op, (unsigned)x * 4u, ro * 4u);
     }
-    if (IMG && win.live) {
-        emit_row(0);
-        emit_row(1);
-        emit_row(2);
+    if (IMG && yb < G.H) {
+        if (win.live) {
+#pragma unroll 1
+            for (int k = 0; k < 3; ++k) emit_shift();
+        }
+        prmin = wave_min_i(prmin); prmax = wave_max_i(prmax);
+        pcmin = wave_min_i(pcmin); pcmax = wave_max_i(pcmax);
+        if (lane == 0) {
+            st.hdrA[tix] = make_int4(rbase, (int)(smask | (npt > 0 ? 0x80000000u : 0u)), cbmin, cbmax);
+            st.hdrB[tix] = make_int4(npt, prmin, prmax, 0);
+            st.cb[tix * kCbStride + kSegRows] = pcmin;
+            st.cb[tix * kCbStride + kSegRows + 1] = pcmax;
+        }
     }
     block_reduce12(gM, partials + ((size_t)n * gridDim.x + blockIdx.x) * 12, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// g_src from the staged segments and points (see ImgStage): one thread per texel column of one source row, all three
+// channels, a wave per 64 columns.  Every texel of g_src is written; the order of the additions is fixed.
+__device__ __forceinline__ int4 buf_load_i32x4(rsrc_t r, unsigned lane_bytes, unsigned uniform_bytes) {
+    return __builtin_bit_cast(int4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, uniform_bytes, 0));
+}
+constexpr int kRedRows = DS_RED_ROWS;   // source rows per wave of the reducer
+constexpr int kMaxCand = 12;            // segments per (row, 64 columns) kept from the scan (2-4 for a smooth warp; max 6 seen)
+constexpr int kCandFirst = 3;           // of those, fetched for all rows at once
+constexpr int kPtBatches = 4;           // point-list batches (64 entries each) whose loads are in flight together
+// The reducer is bound by the latency of its dependent loads (tile records -> a slot's first column -> the slot's values; a
+// point list, batch after batch), not by bytes: one source row per wave (46 k short waves at 12 x 2 x 192 x 640) took 80 us,
+// eight rows per wave handled one after the other 174 us.  So a wave takes 64 columns x kRedRows rows and works in phases that
+// each keep all their loads in flight:
+//   (1) the records of all tiles of its image, 256 at a time: every lane whose tile holds a segment for one of the rows
+//       leaves (tile, slot) in the row's candidate list in LDS (position from a ballot prefix: tile order);
+//   (P) the point lists whose row and column ranges meet the wave's texels, kPtBatches x 64 entries at a time, added to the
+//       wave's texels in LDS (below);
+//   (2) lane f takes entry f of the lists and loads its slot's first column; then the values of the first kCandFirst
+//       candidates of ALL rows are requested together and added in list order (further candidates, rare, row by row).
+__global__ __launch_bounds__(kThreads) void img_reduce_kernel(ImgStage st, int nbx, int Hs, int Ws, float* __restrict__ g_src) {
+    constexpr int kFlat = kRedRows * kMaxCand, kE = (kFlat + 63) / 64;
+    __shared__ int lds_tk[kThreads / 64][kFlat];                // (tile << 4) | slot, row i's list at i * kMaxCand
+    __shared__ float4 lds_pt[kThreads / 64][kRedRows][64];      // the wave's texels: what the points add (x, y, z) and, in
+                                                                // w, the texel's bidding word (below)
+    const int ngroups = (Hs + kRedRows - 1) / kRedRows;
+    const int n = blockIdx.y / ngroups, r0 = (blockIdx.y - n * ngroups) * kRedRows;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int c0 = blockIdx.x * kThreads + wave * 64, col = c0 + lane;
+    if (c0 >= Ws) return;   // wave-uniform
+    const int T = st.nwy * nbx;
+    const long long t_start = (DS_IMG_EXP & 32) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    const int4* hdrA = st.hdrA + (size_t)n * T;
+    const int4* hdrB = st.hdrB + (size_t)n * T;
+    const int* cbn = st.cb + (size_t)n * T * kCbStride;
+    const float* segn = st.seg + (size_t)n * T * kSegRows * kSegFloats;
+    // buffer loads (descriptor in scalar registers + one 32-bit offset per lane) for everything that is fetched in bulk:
+    // with 64-bit addresses the 36 value loads of phase 2 alone held 72 registers and the kernel came to 254 + 52
+    const rsrc_t hA = make_rsrc(hdrA), cbr = make_rsrc(cbn), sgr = make_rsrc(segn);
+    const rsrc_t ptr_ = make_rsrc(st.pt + (size_t)n * T * st.pts_per_tile);
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    float acc[kRedRows][3];
+    int cnt[kRedRows];   // uniform
+    int dg_tiles = 0, dg_pts = 0, dg_hits = 0;
+    bool pt_used = false;    // uniform
+    unsigned epoch = 0;      // uniform: rounds of the point adds so far
+#pragma unroll
+    for (int i = 0; i < kRedRows; ++i) {
+        acc[i][0] = acc[i][1] = acc[i][2] = 0.f;
+        cnt[i] = 0;
+    }
+    constexpr int kU = 4;   // tile records looked at per lane and round: their loads are in flight together
+    for (int base = 0; base < T; base += 64 * kU) {
+        int4 A[kU];
+        // unconditional loads from clamped indices (a predicated load becomes a branch and a wait: the kU loads would go out
+        // one after the other), lanes beyond the last tile get an empty record afterwards
+#pragma unroll
+        for (int u = 0; u < kU; ++u) A[u] = buf_load_i32x4(hA, (unsigned)min(base + u * 64 + lane, T - 1) * 16u, 0u);   // rbase, mask, cbmin, cbmax
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+            if (base + u * 64 + lane >= T) A[u] = make_int4(0, 0, 0, 0);
+        // ---- phase 1: candidate segments of every row, in tile order (no loads in here)
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int t = base + u * 64 + lane;
+            const bool cols = A[u].z - 1 <= c0 + 63 && A[u].w + 64 >= c0;   // the tile's segments may reach these columns
+            const int klo = r0 - A[u].x;
+            const unsigned smk = (unsigned)A[u].y & 0xffffu;
+            const unsigned want = !cols || klo >= kSegRows || klo + kRedRows <= 0 ? 0u
+                                  : (klo >= 0 ? (smk >> klo) : (smk << -klo)) & ((1u << kRedRows) - 1u);
+            if (__ballot(want != 0u) == 0) continue;   // uniform
+#pragma unroll
+            for (int i = 0; i < kRedRows; ++i) {
+                const bool c = (want >> i) & 1u;
+                const unsigned long long m = __ballot(c);
+                if (m == 0) continue;   // uniform
+                const int pos = cnt[i] + __popcll(m & lt_mask);
+                if (c && pos < kMaxCand) lds_tk[wave][i * kMaxCand + pos] = (t << 4) | (klo + i);
+                cnt[i] += __popcll(m);
+            }
+        }
+        // ---- points: lists whose ranges include these rows and columns, tiles in index order, entries in list order
+        unsigned long long pmask[kU];   // uniform: tiles of batch u whose list spans rows of this wave
+        int nptu[kU];
+        {
+            const rsrc_t hB = make_rsrc(hdrB);
+            int4 Bq[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) Bq[u] = buf_load_i32x4(hB, (unsigned)min(base + u * 64 + lane, T - 1) * 16u, 0u);   // npt, prmin, prmax, -
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                pmask[u] = __ballot(A[u].y < 0 && Bq[u].x > 0 && Bq[u].y <= r0 + kRedRows - 1 && r0 <= Bq[u].z);
+                nptu[u] = Bq[u].x;
+            }
+        }
+        // (rolled: unrolled over u the body below existed kU times and the entry registers of all copies were live at once,
+        // 254 + 52 registers = one wave per SIMD)
+#pragma unroll 1
+        for (int u = 0; u < kU; ++u) {
+            unsigned long long pm = 0;
+            int nptv = 0;
+#pragma unroll
+            for (int uu = 0; uu < kU; ++uu) {
+                if (uu == u) {   // uniform
+                    pm = pmask[uu];
+                    nptv = nptu[uu];
+                }
+            }
+            const int tb = base + u * 64;
+            while (pm) {
+                const int m = __builtin_ctzll(pm);
+                pm &= pm - 1;
+                const int t = tb + m;
+                if (cbn[t * kCbStride + kSegRows] > c0 + 63 || cbn[t * kCbStride + kSegRows + 1] + 1 < c0) continue;   // uniform
+                const int npts = __builtin_amdgcn_readlane(nptv, m);
+                if (DS_IMG_EXP & 32) { dg_tiles += 1; dg_pts += npts; }
+                const unsigned pl = (unsigned)t * (unsigned)st.pts_per_tile * 32u;   // this tile's list inside the image's
+                for (int pb = 0; pb < npts; pb += 64 * kPtBatches) {
+                    int4 ea[kPtBatches], eb[kPtBatches];   // whole entries, from clamped indices
+#pragma unroll
+                    for (int q = 0; q < kPtBatches; ++q) {
+                        const int e = min(pb + q * 64 + lane, npts - 1);
+                        ea[q] = buf_load_i32x4(ptr_, (unsigned)e * 32u, pl);          // row, col, v[0][0], v[0][1]
+                        eb[q] = buf_load_i32x4(ptr_, (unsigned)e * 32u, pl + 16u);    // v[1][0], v[1][1], v[2][0], v[2][1]
+                    }
+#pragma unroll
+                    for (int q = 0; q < kPtBatches; ++q) {
+                        const int pr = ea[q].x - r0, pc = ea[q].y;
+                        const bool hit = pb + q * 64 + lane < npts && pr >= 0 && pr < kRedRows && pc + 1 >= c0 && pc <= c0 + 63;
+                        const unsigned long long hits = __ballot(hit);
+                        if (DS_IMG_EXP & 32) dg_hits += __popcll(hits);
+                        if (hits == 0) continue;   // uniform
+                        const float pv[6] = {__builtin_bit_cast(float, ea[q].z), __builtin_bit_cast(float, ea[q].w),
+                                             __builtin_bit_cast(float, eb[q].x), __builtin_bit_cast(float, eb[q].y),
+                                             __builtin_bit_cast(float, eb[q].z), __builtin_bit_cast(float, eb[q].w)};
+                        if (!pt_used) {   // uniform: first entries for this wave's texels
+                            pt_used = true;
+#pragma unroll
+                            for (int i = 0; i < kRedRows; ++i) lds_pt[wave][i][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                        // The entries of this batch are added to the wave's texels in LDS, all lanes at once, first every
+                        // entry's left texel, then its right one.  Entries on the SAME texel have to be added one after
+                        // the other and in list order: each round the pending lanes bid for their texel with an integer
+                        // max (order-independent, unlike a float atomic) of (round, 63 - lane); the lowest lane of every
+                        // texel wins, adds with a plain read-modify-write, and leaves.  Rounds = the largest number of
+                        // entries on one texel (pass 1 has summed the long runs already).  One thread adding hit after
+                        // hit instead: 600 cycles a hit, 600 k cycles for the waves under an all-points tile.
+#pragma unroll
+                        for (int side = 0; side < 2; ++side) {
+                            const int cx = pc + side - c0;
+                            bool pending = hit && cx >= 0 && cx <= 63;
+                            const int rr = min(max(pr, 0), kRedRows - 1), cc = min(max(cx, 0), 63);
+                            float4* cell = &lds_pt[wave][rr][cc];
+                            unsigned* tag = reinterpret_cast<unsigned*>(&lds_pt[wave][rr][cc].w);
+                            while (__ballot(pending)) {
+                                epoch += 1u;
+                                const unsigned bid = (epoch << 6) | (unsigned)(63 - lane);
+                                if (pending) __hip_atomic_fetch_max(tag, bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                asm volatile("" ::: "memory");   // (the word is also cell->w: nothing kept across the bid)
+                                const float4 cur = *cell;        // the texel and its bidding word in one read
+                                const bool win = pending && __builtin_bit_cast(unsigned, cur.w) == bid;
+                                if (win) *cell = make_float4(cur.x + pv[side], cur.y + pv[2 + side], cur.z + pv[4 + side], cur.w);
+                                asm volatile("" ::: "memory");
+                                pending = pending && !win;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- phase 2: lane f holds entry f of the candidate lists and fetches the first column of its slot
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int tkf[kE], cbf[kE];
+#pragma unroll
+    for (int e = 0; e < kE; ++e) {
+        const int f = min(e * 64 + lane, kFlat - 1), fi = f / kMaxCand, fq = f - fi * kMaxCand;
+        int ci = 0;
+#pragma unroll
+        for (int i = 0; i < kRedRows; ++i) ci = fi == i ? cnt[i] : ci;
+        tkf[e] = fq < ci ? lds_tk[wave][f] : 0;      // (an unused entry reads tile 0, slot 0: memory that exists)
+        cbf[e] = __builtin_amdgcn_raw_buffer_load_b32(cbr, (unsigned)((tkf[e] >> 4) * kCbStride + (tkf[e] & 15)) * 4u, 0u, 0);
+    }
+    auto entry = [&](int f, int& tk, int& cb) {   // f is a compile-time constant wherever this is called
+        tk = __builtin_amdgcn_readlane(tkf[f >> 6], f & 63);
+        cb = __builtin_amdgcn_readlane(cbf[f >> 6], f & 63);
+    };
+    {
+        float v[kRedRows][kCandFirst][3];
+        bool in[kRedRows][kCandFirst];
+#pragma unroll
+        for (int i = 0; i < kRedRows; ++i) {
+#pragma unroll
+            for (int q = 0; q < kCandFirst; ++q) {
+                int tk, cb;
+                entry(i * kMaxCand + q, tk, cb);
+                const int j = col - (cb - 1);
+                in[i][q] = q < cnt[i] && j >= 0 && j <= 65;
+                const unsigned slot = (unsigned)((tk >> 4) * kSegRows + (tk & 15)) * (unsigned)kSegFloats;   // uniform
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[i][q][c] = buf_load_f32(sgr, (unsigned)min(max(j, 0), 65) * 4u, slot + c * 66u);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kRedRows; ++i)
+#pragma unroll
+            for (int q = 0; q < kCandFirst; ++q)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[i][c] += in[i][q] ? v[i][q][c] : 0.0f;   // (+ 0.0f where nothing was found: exact)
+    }
+    bool more = false, over = false;
+#pragma unroll
+    for (int i = 0; i < kRedRows; ++i) {
+        more = more || cnt[i] > kCandFirst;
+        over = over || cnt[i] > kMaxCand;
+    }
+    if (more) {   // uniform: the rest of the lists, row by row, three candidates at a time (rolled: this is the rare path)
+#pragma unroll 1
+        for (int i = 0; i < kRedRows; ++i) {
+            int ci = 0;
+#pragma unroll
+            for (int ii = 0; ii < kRedRows; ++ii) ci = ii == i ? cnt[ii] : ci;
+            const int nc = min(ci, kMaxCand);
+            float rest[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int q0 = kCandFirst; q0 < nc; q0 += 3) {
+                float v[3][3];
+                bool in[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int f = i * kMaxCand + min(q0 + q, nc - 1);
+                    int tk = 0, cb = 0;
+#pragma unroll
+                    for (int e = 0; e < kE; ++e) {
+                        if ((f >> 6) == e) {   // uniform
+                            tk = __builtin_amdgcn_readlane(tkf[e], f & 63);
+                            cb = __builtin_amdgcn_readlane(cbf[e], f & 63);
+                        }
+                    }
+                    const int j = col - (cb - 1);
+                    in[q] = q0 + q < nc && j >= 0 && j <= 65;
+                    const unsigned slot = (unsigned)((tk >> 4) * kSegRows + (tk & 15)) * (unsigned)kSegFloats;   // uniform
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[q][c] = buf_load_f32(sgr, (unsigned)min(max(j, 0), 65) * 4u, slot + c * 66u);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) rest[c] += in[q] ? v[q][c] : 0.0f;
+            }
+#pragma unroll
+            for (int ii = 0; ii < kRedRows; ++ii) {
+                if (ii == i) {   // uniform
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[ii][c] += rest[c];
+                }
+            }
+        }
+    }
+    // a row with more candidates than the list holds (a strongly minifying warp): those beyond it, found again, in tile order
+    if (over) {   // uniform
+        for (int i = 0; i < kRedRows; ++i) {
+            int seen = 0;
+            for (int tb = 0; tb < T; tb += 64) {
+                const int t = tb + lane;
+                const int4 a = hdrA[min(t, T - 1)];
+                const int k = r0 + i - a.x;
+                const bool c = t < T && k >= 0 && k < kSegRows && ((((unsigned)a.y & 0xffffu) >> k) & 1u) &&
+                               a.z - 1 <= c0 + 63 && a.w + 64 >= c0;
+                unsigned long long todo = __ballot(c);
+                while (todo) {
+                    const int m = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    if (seen++ < kMaxCand) continue;   // already added from the list
+                    const int kk = __builtin_amdgcn_readlane(k, m);
+                    const int j = col - (cbn[(tb + m) * kCbStride + kk] - 1);
+                    if (j >= 0 && j <= 65) {
+                        const float* p = segn + ((size_t)(tb + m) * kSegRows + kk) * kSegFloats + j;
+                        for (int ii = 0; ii < kRedRows; ++ii)
+                            if (ii == i)
+                                for (int c = 0; c < 3; ++c) acc[ii][c] += p[c * 66];
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("" ::: "memory");
+    if (pt_used) {   // uniform
+#pragma unroll
+        for (int i = 0; i < kRedRows; ++i) {
+            const float4 cell = lds_pt[wave][i][lane];
+            acc[i][0] += cell.x;
+            acc[i][1] += cell.y;
+            acc[i][2] += cell.z;
+        }
+    }
+    if (DS_IMG_EXP & 32) {   // diagnostic build: cycles this wave lived (channel 0), point tiles / points scanned / hits
+        acc[0][0] = (float)((long long)__builtin_amdgcn_s_memtime() - t_start);
+        acc[0][1] = (float)dg_tiles;
+        acc[0][2] = (float)dg_pts;
+        if (kRedRows > 1) acc[kRedRows > 1 ? 1 : 0][0] = (float)dg_hits;
+    }
+    if (col < Ws) {
+#pragma unroll
+        for (int i = 0; i < kRedRows; ++i) {
+            if (r0 + i < Hs) {
+                float* o = g_src + ((size_t)n * 3 * Hs + r0 + i) * Ws + col;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o[(size_t)c * Hs * Ws] = acc[i][c];
+            }
+        }
+    }
 }
 
 // backward of reproject_from_depth alone: g_coords (N,H,W,2) -> g_depth, pose partials
@@ -584,6 +1036,35 @@ inline int warp_tiles(int H, int W, int rows) {  // blocks per image: 64 columns
     return ((W + 63) / 64) * ((H + per_block - 1) / per_block);
 }
 
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// small launches (fewer workgroups than would give every SIMD two waves) take the short tiles; only the 3-channel kernels
+// are instantiated for them (the generic-C kernel keeps kBwdRows, and its grid with it)
+inline bool bwd_small(int N, int C, int H, int W) {
+    return C == 3 && (long long)warp_tiles(H, W, kBwdRows) * N < 2ll * ds::cu_count();
+}
+
+// where the staging of the image gradient lies in a workspace that starts with the pose-gradient partials
+struct ImgLayout {
+    size_t off_a, off_b, off_cb, off_seg, off_pt, total;
+    int nwy, pts_per_tile;
+};
+inline ImgLayout img_layout(int N, int H, int W) {
+    ImgLayout L;
+    const int rows = bwd_small(N, 3, H, W) ? kBwdRowsSmall : kBwdRows;
+    L.nwy = (H + rows - 1) / rows;
+    L.pts_per_tile = 198 * (rows + 1);   // every finished window row misplaced (66 owned + outer columns, 3 per pixel row + 3)
+                                         // or every pixel a point (2 x 64 per row): the larger, per row
+    const size_t tiles = (size_t)N * L.nwy * ((W + 63) / 64);
+    L.off_a = align256(ds_warp_bwd_workspace_bytes(N, H, W));
+    L.off_b = align256(L.off_a + tiles * sizeof(int4));
+    L.off_cb = align256(L.off_b + tiles * sizeof(int4));
+    L.off_seg = align256(L.off_cb + tiles * kCbStride * sizeof(int));
+    L.off_pt = align256(L.off_seg + tiles * kSegRows * kSegFloats * sizeof(float));
+    L.total = L.off_pt + tiles * L.pts_per_tile * sizeof(PtEntry);
+    return L;
+}
+
 inline bool bad_dims(int N, int C, int Hs, int Ws, int H, int W) {
     return N <= 0 || C <= 0 || Hs < 2 || Ws < 2 || H <= 0 || W <= 0 || N > 65535 ||
            (long long)H * W > (1ll << 30) || (long long)Hs * Ws > (1ll << 30) ||
@@ -649,6 +1130,12 @@ size_t ds_warp_bwd_workspace_bytes(int N, int H, int W) {
     return (size_t)N * (a > b ? a : b) * 12 * sizeof(float);
 }
 
+size_t ds_warp_bwd_image_workspace_bytes(int N, int C, int Hs, int Ws, int H, int W) {
+    if (N <= 0 || C <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0) return 0;
+    if (C != 3) return ds_warp_bwd_workspace_bytes(N, H, W);   // other channel counts scatter with float atomics
+    return img_layout(N, H, W).total;
+}
+
 int ds_warp_bwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
                 const float* g_warped, int N, int C, int Hs, int Ws, int H, int W, float* g_depth, float* g_pose,
                 float* g_src, void* workspace, size_t workspace_bytes, void* stream) {
@@ -700,30 +1187,44 @@ int ds::warp_bwd_partials(const float* K, const float* Kinv, const float* pose, 
     if (!K || !Kinv || !pose || !depth || !src || !g_warped || !g_depth || bad_dims(N, C, Hs, Ws, H, W))
         return DS_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < ds_warp_bwd_workspace_bytes(N, H, W)) return DS_ERR_WORKSPACE;
+    const bool stage = g_src && C == 3;   // the image gradient without atomics (see ImgStage)
+    if (stage && (((uintptr_t)workspace & 15) || workspace_bytes < ds_warp_bwd_image_workspace_bytes(N, C, Hs, Ws, H, W)))
+        return DS_ERR_WORKSPACE;
     const WarpGeom G = warp_geom(Hs, Ws, H, W);
-    // small launches (fewer workgroups than would give every SIMD two waves) take the short tiles; only the 3-channel
-    // kernels are instantiated for them (the generic-C kernel keeps kBwdRows, and its grid with it)
-    const bool small = C == 3 && (long long)warp_tiles(H, W, kBwdRows) * N < 2ll * ds::cu_count();
+    const bool small = bwd_small(N, C, H, W);
     const int nblk = warp_tiles(H, W, small ? kBwdRowsSmall : kBwdRows);
     dim3 g(nblk, N), b(kThreads);
     float* partials = (float*)workspace;
-    if (C == 3 && g_src) {
+    ImgStage st{};
+    if (stage) {
+        const ImgLayout L = img_layout(N, H, W);
+        char* w = (char*)workspace;
+        st.hdrA = (int4*)(w + L.off_a);
+        st.hdrB = (int4*)(w + L.off_b);
+        st.cb = (int*)(w + L.off_cb);
+        st.seg = (float*)(w + L.off_seg);
+        st.pt = (PtEntry*)(w + L.off_pt);
+        st.nwy = L.nwy;
+        st.pts_per_tile = L.pts_per_tile;
         if (small)
             hipLaunchKernelGGL((warp_bwd_kernel<3, true, kBwdRowsSmall>), g, b, 0, stream, K, Kinv, pose, depth, src, g_warped, C,
-                               G, g_depth, g_src, partials);
+                               G, g_depth, g_src, partials, st);
         else
             hipLaunchKernelGGL((warp_bwd_kernel<3, true>), g, b, 0, stream, K, Kinv, pose, depth, src, g_warped, C, G, g_depth,
-                               g_src, partials);
+                               g_src, partials, st);
+        DS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(img_reduce_kernel, dim3((Ws + kThreads - 1) / kThreads, (unsigned)(N * ((Hs + kRedRows - 1) / kRedRows))),
+                           dim3(kThreads), 0, stream, st, G.nbx, Hs, Ws, g_src);
     } else if (C == 3) {
         if (small)
             hipLaunchKernelGGL((warp_bwd_kernel<3, false, kBwdRowsSmall>), g, b, 0, stream, K, Kinv, pose, depth, src, g_warped,
-                               C, G, g_depth, nullptr, partials);
+                               C, G, g_depth, nullptr, partials, st);
         else
             hipLaunchKernelGGL(warp_bwd_kernel<3>, g, b, 0, stream, K, Kinv, pose, depth, src, g_warped, C, G, g_depth, nullptr,
-                               partials);
+                               partials, st);
     } else {
         hipLaunchKernelGGL(warp_bwd_kernel<0>, g, b, 0, stream, K, Kinv, pose, depth, src, g_warped, C, G, g_depth, g_src,
-                           partials);
+                           partials, st);
     }
     DS_CHECK_LAUNCH();
     *nblk_out = nblk;

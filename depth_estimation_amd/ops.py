@@ -156,8 +156,13 @@ class _Warp(torch.autograd.Function):
         g = L.dev_f32(g, "grad")
         gd = torch.empty_like(depth)
         gp = torch.empty_like(pose)
-        gs = torch.zeros_like(src) if ctx.needs_input_grad[4] else None
-        nb = L.lib().ds_warp_bwd_workspace_bytes(n, h, w)
+        gs = None
+        if ctx.needs_input_grad[4]:
+            # C = 3: every texel is written (no float atomics, run-to-run identical); other C: atomics onto zeros
+            gs = torch.empty_like(src) if c == 3 else torch.zeros_like(src)
+            nb = L.lib().ds_warp_bwd_image_workspace_bytes(n, c, hs, ws, h, w)
+        else:
+            nb = L.lib().ds_warp_bwd_workspace_bytes(n, h, w)
         wsb = L.workspace.get(nb, depth.device)
         L.check(L.lib().ds_warp_bwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
                                     g.data_ptr(), n, c, hs, ws, h, w, gd.data_ptr(), gp.data_ptr(), L.ptr(gs),

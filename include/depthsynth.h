@@ -73,9 +73,18 @@ int ds_warp_fwd(const float* K, const float* Kinv, const float* pose, const floa
 
 /* workspace for the pose-gradient partials of ds_warp_bwd and ds_reproject_bwd */
 size_t ds_warp_bwd_workspace_bytes(int N, int H, int W);
+/* workspace of ds_warp_bwd WITH the source-image gradient (g_src != NULL): for C == 3 the pose partials plus the staging of
+ * the scatter -- per wave of the launch (64 columns x 8 rows of pixels) a record, 16 row slots of 66 x 3 floats and a point
+ * list: about 140 bytes per warped pixel, sized for the worst case (every pixel leaving its wave on its own); only what a
+ * warp actually stages is touched (~16 bytes per pixel for a smooth warp).  16-byte aligned, need not be initialised.
+ * Other C: = ds_warp_bwd_workspace_bytes. */
+size_t ds_warp_bwd_image_workspace_bytes(int N, int C, int Hs, int Ws, int H, int W);
 
-/* autograd of ds_warp_fwd: g_depth (N,H,W), g_pose (N,3,4) (deterministic two-stage reduction, no
- * atomics), g_src (N,C,Hs,Ws) optional (NULL to skip; zero-filled by the caller otherwise). */
+/* autograd of ds_warp_fwd: g_depth (N,H,W), g_pose (N,3,4) (deterministic two-stage reduction, no atomics), g_src
+ * (N,C,Hs,Ws) optional (NULL to skip).  C == 3: g_src is formed without atomics -- every texel is written once, the sum of
+ * the staged contributions in a fixed order, bit-identical from run to run; it need not be cleared, and the workspace must
+ * have ds_warp_bwd_image_workspace_bytes.  Other channel counts: float atomics onto a g_src the caller has zero-filled
+ * (order-dependent in the last bits). */
 int ds_warp_bwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
                 const float* g_warped, int N, int C, int Hs, int Ws, int H, int W, float* g_depth, float* g_pose,
                 float* g_src, void* workspace, size_t workspace_bytes, void* stream);
@@ -188,9 +197,11 @@ int ds_loss_step_bwd(const float* K, const float* Kinv, const float* pose, const
  * g_warped (B,S,3,H,W) is scratch; for S <= 3 without g_src the gradient w.r.t. the warped images passes from the loss
  * kernel's waves to the warp's autograd inside one kernel, the buffer is left untouched and may be NULL (with g_src, or
  * S = 4, NULL is DS_ERR_INVALID_ARG).  g_src (B,S,3,H,W), optional (NULL
- * to skip): the gradient w.r.t. the source images through the warp (cleared and accumulated here; float atomics, as in
- * ds_warp_bwd).  workspace 16-byte aligned, sized by ds_loss_step_fwdbwd_workspace_bytes. */
+ * to skip): the gradient w.r.t. the source images through the warp (every texel written, no atomics, bit-identical
+ * from run to run: see ds_warp_bwd).  workspace 16-byte aligned, sized by ds_loss_step_fwdbwd_workspace_bytes, or by
+ * ds_loss_step_fwdbwd_image_workspace_bytes when g_src is given. */
 size_t ds_loss_step_fwdbwd_workspace_bytes(int B, int S, int H, int W);
+size_t ds_loss_step_fwdbwd_image_workspace_bytes(int B, int S, int H, int W);
 int ds_loss_step_fwdbwd(const float* K, const float* Kinv, const float* pose, const float* depth, const float* src,
                         const float* target, const float* g_sums, int B, int S, int H, int W, float* warped,
                         float* out_loss, float* idt_loss, uint8_t* aux, float* sums, float* g_warped, float* g_depth,

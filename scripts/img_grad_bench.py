@@ -1,29 +1,31 @@
-"""ds_warp_bwd with the image gradient: random per-pixel depth (bench.py's synthetic batch: a few near pixels among far
-ones in every wave row) against a smooth depth map (what a network predicts), same poses."""
-import sys, os, torch
+"""Per-call times of the step with the source-image gradient at bench.py's config-3 finest level (B=12, S=2, 192x640) with
+bench.py's random per-pixel depth and with a smooth depth map: HIP events around each C call, 200 steps."""
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
 import bench
 import depth_estimation_amd as de
+
 dev = torch.device("cuda", 0)
-for B, S, H, W in ((12, 2, 192, 640), (64, 2, 320, 1024)):
-    for kind in ("random", "smooth", "none"):
-        sc = bench.Scale(de, B, S, H, W, dev, 0, kind != "none")
-        if kind == "smooth":
-            yy, xx = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
-            sc.depth.copy_((4 + 60 * (1 - yy / H) + 6 * torch.sin(xx / 40.0)).expand(B, S, H, W))
-        st = torch.cuda.current_stream().cuda_stream
-        for _ in range(3):
-            sc.step(st)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 30
-        tot = 0.0
-        for _ in range(n):
-            if sc.g_src is not None:
-                sc.g_src.zero_()
-            e0.record()
-            sc.calls["warp_bwd"](st)
-            e1.record()
-            torch.cuda.synchronize()
-            tot += e0.elapsed_time(e1)
-        print(f"B={B} {H}x{W} depth={kind:7s} warp_bwd {tot / n * 1e3:8.1f} us")
+st = torch.cuda.Stream()
+torch.cuda.set_stream(st)
+for kind in (sys.argv[1:] or ["random", "smooth"]):
+    sc = bench.Scale(de, 12, 2, 192, 640, dev, 0, True)
+    if kind == "smooth":
+        sc.depth.copy_(torch.linspace(80, 5, 192, device=dev).view(1, 1, 192, 1).expand_as(sc.depth) + 0.5 * torch.rand_like(sc.depth))
+    s = st.cuda_stream
+    for _ in range(300):
+        sc.step(s)
+    torch.cuda.synchronize()
+    ev = {n: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)] for n in sc.names}
+    for i in range(200):
+        for n in sc.names:
+            ev[n][i][0].record(); sc.calls[n](s); ev[n][i][1].record()
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(200):
+        sc.step(s)
+    torch.cuda.synchronize()
+    one = (time.perf_counter() - t0) / 200 * 1e3
+    print(kind, {n: round(sum(a.elapsed_time(b) for a, b in ev[n]) / 200, 4) for n in sc.names}, "one call", round(one, 4), "ms")

@@ -58,9 +58,13 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&g_depth, N * HW * 4)); CK(hipMalloc(&g_pose, N * 48));
     std::vector<float> ones(B, 1.f); CK(hipMalloc(&g_sums, B * 4)); CK(hipMemcpy(g_sums, ones.data(), B * 4, hipMemcpyHostToDevice));
     size_t n1 = ws_loss(B, H, W), n2 = ws_warp(N, H, W);
+    float* g_src = nullptr;  // DS_KBENCH_IMG=1: also form the source-image gradient
+    typedef size_t (*ws6_t)(int, int, int, int, int, int);
+    if (getenv("DS_KBENCH_IMG")) {
+        CK(hipMalloc(&g_src, N * 3 * HW * 4)); CK(hipMemset(g_src, 0, N * 3 * HW * 4));
+        if (auto wsi = (ws6_t)dlsym(h, "ds_warp_bwd_image_workspace_bytes")) n2 = wsi(N, 3, H, W, H, W);   // round 3: staging
+    }
     CK(hipMalloc(&w1, n1 ? n1 : 4)); CK(hipMalloc(&w2, n2 ? n2 : 4));
-    float* g_src = nullptr;  // DS_KBENCH_IMG=1: also scatter the source-image gradient
-    if (getenv("DS_KBENCH_IMG")) { CK(hipMalloc(&g_src, N * 3 * HW * 4)); CK(hipMemset(g_src, 0, N * 3 * HW * 4)); }
     hipStream_t st = 0;
     hipEvent_t e[5]; for (auto& x : e) CK(hipEventCreate(&x));
     double t[4] = {0, 0, 0, 0};
@@ -166,7 +170,9 @@ int main(int argc, char** argv) {
         auto stepf = (step_t)dlsym(h, "ds_loss_step_fwdbwd");
         auto stepws = (ws4_t)dlsym(h, "ds_loss_step_fwdbwd_workspace_bytes");
         if (stepf && stepws) {
-            size_t n3 = stepws(B, S, H, W); void* w3; CK(hipMalloc(&w3, n3));
+            size_t n3 = stepws(B, S, H, W);
+            if (g_src) if (auto wsi = (ws4_t)dlsym(h, "ds_loss_step_fwdbwd_image_workspace_bytes")) n3 = wsi(B, S, H, W);
+            void* w3; CK(hipMalloc(&w3, n3));
             double one = wall([&] {
                 int rc = stepf(K, Kinv, pose, depth, src, tgt, nullptr, B, S, H, W, warped, out, idt, aux, sums, g_warped, g_depth, g_pose, g_src, w3, n3, s1);
                 if (rc) { fprintf(stderr, "ds_loss_step_fwdbwd rc=%d\n", rc); exit(1); }
