@@ -20,6 +20,14 @@ for wl in b12_s2_192x640_fwdbwd b64_s2_320x1024_fwdbwd; do
   scripts/pmc_pass.sh ${tag}_SQ1_${wl} $wl SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY || exit 1
   scripts/pmc_pass.sh ${tag}_SQ2_${wl} $wl SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 || exit 1
 done
+# the plane sweep (train.py:49-60 at the reference's shape): resize + sweep + resize, the sweep kernel dominates
+wl=b12_s2_sweep80_96x320
+timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --workload $wl --no-cpu > $out/bench_sweep.json 2> $out/bench_sweep.err || exit 1
+for c in FETCH_SIZE WRITE_SIZE; do
+  scripts/pmc_pass.sh ${tag}_${c}_${wl} $wl $c || exit 1
+done
+scripts/pmc_pass.sh ${tag}_SQ1_${wl} $wl SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY || exit 1
+scripts/pmc_pass.sh ${tag}_SQ2_${wl} $wl SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 || exit 1
 # the finest pyramid level with the image gradient (config 3's dominant launch: the scattering warp backward)
 for c in FETCH_SIZE WRITE_SIZE; do
   PMC_EXTRA="--image-grad" scripts/pmc_pass.sh ${tag}_${c}_imggrad b12_s2_192x640_fwdbwd $c || exit 1
