@@ -26,26 +26,37 @@ def _chk_cam(K, Kinv, pose, n):
 # ----------------------------------------------------------------------------------------------------
 # synthesis.construct_pose_batch
 # ----------------------------------------------------------------------------------------------------
+# (the *_impl functions are the C-ABI calls; the autograd.Function classes below and the torch.library registrations in
+# custom_ops.py both wrap them)
+def pose_from_vec_impl(vec):
+    vec = L.dev_f32(vec, "pose_vectors")
+    if vec.dim() != 2 or vec.shape[1] != 6:
+        raise RuntimeError(f"pose_vectors must be (N,6), got {tuple(vec.shape)}")
+    n = vec.shape[0]
+    pose = torch.empty(n, 3, 4, dtype=torch.float32, device=vec.device)
+    L.check(L.lib().ds_pose_from_vec_fwd(vec.data_ptr(), n, pose.data_ptr(), L.stream()), "ds_pose_from_vec_fwd")
+    return vec, pose
+
+
+def pose_from_vec_bwd_impl(vec, g):
+    g = L.dev_f32(g, "grad")
+    gv = torch.empty_like(vec)
+    L.check(L.lib().ds_pose_from_vec_bwd(vec.data_ptr(), g.data_ptr(), vec.shape[0], gv.data_ptr(), L.stream()),
+            "ds_pose_from_vec_bwd")
+    return gv
+
+
 class _PoseFromVec(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vec):
-        vec = L.dev_f32(vec, "pose_vectors")
-        if vec.dim() != 2 or vec.shape[1] != 6:
-            raise RuntimeError(f"pose_vectors must be (N,6), got {tuple(vec.shape)}")
-        n = vec.shape[0]
-        pose = torch.empty(n, 3, 4, dtype=torch.float32, device=vec.device)
-        L.check(L.lib().ds_pose_from_vec_fwd(vec.data_ptr(), n, pose.data_ptr(), L.stream()), "ds_pose_from_vec_fwd")
+        vec, pose = pose_from_vec_impl(vec)
         ctx.save_for_backward(vec)
         return pose
 
     @staticmethod
     def backward(ctx, g):
         (vec,) = ctx.saved_tensors
-        g = L.dev_f32(g, "grad")
-        gv = torch.empty_like(vec)
-        L.check(L.lib().ds_pose_from_vec_bwd(vec.data_ptr(), g.data_ptr(), vec.shape[0], gv.data_ptr(), L.stream()),
-                "ds_pose_from_vec_bwd")
-        return gv
+        return pose_from_vec_bwd_impl(vec, g)
 
 
 def pose_from_vec(vec: torch.Tensor) -> torch.Tensor:
@@ -132,41 +143,51 @@ def grid_sample_(src: torch.Tensor, grid: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------------
 # fused reproject + sample
 # ----------------------------------------------------------------------------------------------------
+def warp_impl(K, Kinv, pose, depth, src):
+    depth, src = L.dev_f32(depth, "depth"), L.dev_f32(src, "src")
+    n, h, w = depth.shape
+    if src.dim() != 4 or src.shape[0] != n:
+        raise RuntimeError(f"src must be ({n},C,Hs,Ws), got {tuple(src.shape)}")
+    _, c, hs, ws = src.shape
+    K, Kinv, pose = _chk_cam(K, Kinv, pose, n)
+    L.same_device(depth, src, K, Kinv, pose)
+    warped = torch.empty(n, c, h, w, dtype=torch.float32, device=src.device)
+    L.check(L.lib().ds_warp_fwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(), n, c,
+                                hs, ws, h, w, warped.data_ptr(), L.stream()), "ds_warp_fwd")
+    return (K, Kinv, pose, depth, src), warped
+
+
+def warp_bwd_impl(K, Kinv, pose, depth, src, g, need_src: bool):
+    """-> (g_pose, g_depth, g_src or None); the arguments are warp_impl's checked tensors."""
+    n, h, w = depth.shape
+    _, c, hs, ws = src.shape
+    g = L.dev_f32(g, "grad")
+    gd = torch.empty_like(depth)
+    gp = torch.empty_like(pose)
+    gs = None
+    if need_src:
+        # C = 3: every texel is written (no float atomics, run-to-run identical); other C: atomics onto zeros
+        gs = torch.empty_like(src) if c == 3 else torch.zeros_like(src)
+        nb = L.lib().ds_warp_bwd_image_workspace_bytes(n, c, hs, ws, h, w)
+    else:
+        nb = L.lib().ds_warp_bwd_workspace_bytes(n, h, w)
+    wsb = L.workspace.get(nb, depth.device)
+    L.check(L.lib().ds_warp_bwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
+                                g.data_ptr(), n, c, hs, ws, h, w, gd.data_ptr(), gp.data_ptr(), L.ptr(gs),
+                                wsb.data_ptr(), nb, L.stream()), "ds_warp_bwd")
+    return gp, gd, gs
+
+
 class _Warp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, K, Kinv, pose, depth, src):
-        depth, src = L.dev_f32(depth, "depth"), L.dev_f32(src, "src")
-        n, h, w = depth.shape
-        if src.dim() != 4 or src.shape[0] != n:
-            raise RuntimeError(f"src must be ({n},C,Hs,Ws), got {tuple(src.shape)}")
-        _, c, hs, ws = src.shape
-        K, Kinv, pose = _chk_cam(K, Kinv, pose, n)
-        L.same_device(depth, src, K, Kinv, pose)
-        warped = torch.empty(n, c, h, w, dtype=torch.float32, device=src.device)
-        L.check(L.lib().ds_warp_fwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(), n, c,
-                                    hs, ws, h, w, warped.data_ptr(), L.stream()), "ds_warp_fwd")
-        ctx.save_for_backward(K, Kinv, pose, depth, src)
+        saved, warped = warp_impl(K, Kinv, pose, depth, src)
+        ctx.save_for_backward(*saved)
         return warped
 
     @staticmethod
     def backward(ctx, g):
-        K, Kinv, pose, depth, src = ctx.saved_tensors
-        n, h, w = depth.shape
-        _, c, hs, ws = src.shape
-        g = L.dev_f32(g, "grad")
-        gd = torch.empty_like(depth)
-        gp = torch.empty_like(pose)
-        gs = None
-        if ctx.needs_input_grad[4]:
-            # C = 3: every texel is written (no float atomics, run-to-run identical); other C: atomics onto zeros
-            gs = torch.empty_like(src) if c == 3 else torch.zeros_like(src)
-            nb = L.lib().ds_warp_bwd_image_workspace_bytes(n, c, hs, ws, h, w)
-        else:
-            nb = L.lib().ds_warp_bwd_workspace_bytes(n, h, w)
-        wsb = L.workspace.get(nb, depth.device)
-        L.check(L.lib().ds_warp_bwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
-                                    g.data_ptr(), n, c, hs, ws, h, w, gd.data_ptr(), gp.data_ptr(), L.ptr(gs),
-                                    wsb.data_ptr(), nb, L.stream()), "ds_warp_bwd")
+        gp, gd, gs = warp_bwd_impl(*ctx.saved_tensors, g, ctx.needs_input_grad[4])
         return None, None, gp, gd, gs
 
 
@@ -213,45 +234,53 @@ def ssim_loss(preds, targets) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------------
 # metrics.reprojection_loss (batched: preds (B,S,3,H,W))
 # ----------------------------------------------------------------------------------------------------
+def reprojection_loss_impl(preds, targets, shared_target: bool):
+    preds, targets = L.dev_f32(preds, "preds"), L.dev_f32(targets, "targets")
+    L.same_device(preds, targets)
+    b, s, c, h, w = preds.shape
+    if c != 3:
+        raise RuntimeError(f"reprojection_loss kernels are built for 3 channels, got {c}")
+    hw = h * w
+    if shared_target:
+        if targets.shape != (b, c, h, w):
+            raise RuntimeError(f"targets must be ({b},{c},{h},{w}), got {tuple(targets.shape)}")
+        sb, ss = c * hw, 0
+    else:
+        if targets.shape != preds.shape:
+            raise RuntimeError(f"targets {tuple(targets.shape)} must match preds {tuple(preds.shape)}")
+        sb, ss = s * c * hw, c * hw
+    out = torch.empty(b, h, w, dtype=torch.float32, device=preds.device)
+    aux = torch.empty(b, h, w, dtype=torch.uint8, device=preds.device)
+    L.check(L.lib().ds_reprojection_loss_fwd(preds.data_ptr(), targets.data_ptr(), sb, ss, b, s, h, w, out.data_ptr(),
+                                             aux.data_ptr(), L.stream()), "ds_reprojection_loss_fwd")
+    return (preds, targets, aux), (sb, ss), out
+
+
+def reprojection_loss_bwd_impl(preds, targets, aux, strides, g_out):
+    b, s, c, h, w = preds.shape
+    sb, ss = strides
+    g_out = L.dev_f32(g_out, "grad")
+    gp = torch.empty_like(preds)
+    L.check(L.lib().ds_reprojection_loss_bwd(preds.data_ptr(), targets.data_ptr(), sb, ss, g_out.data_ptr(),
+                                             aux.data_ptr(), b, s, h, w, gp.data_ptr(), L.stream()),
+            "ds_reprojection_loss_bwd")
+    return gp
+
+
 class _ReprojLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, preds, targets, shared_target: bool):
-        preds, targets = L.dev_f32(preds, "preds"), L.dev_f32(targets, "targets")
-        L.same_device(preds, targets)
-        b, s, c, h, w = preds.shape
-        if c != 3:
-            raise RuntimeError(f"reprojection_loss kernels are built for 3 channels, got {c}")
-        hw = h * w
-        if shared_target:
-            if targets.shape != (b, c, h, w):
-                raise RuntimeError(f"targets must be ({b},{c},{h},{w}), got {tuple(targets.shape)}")
-            sb, ss = c * hw, 0
-        else:
-            if targets.shape != preds.shape:
-                raise RuntimeError(f"targets {tuple(targets.shape)} must match preds {tuple(preds.shape)}")
-            sb, ss = s * c * hw, c * hw
-        out = torch.empty(b, h, w, dtype=torch.float32, device=preds.device)
-        aux = torch.empty(b, h, w, dtype=torch.uint8, device=preds.device)
-        L.check(L.lib().ds_reprojection_loss_fwd(preds.data_ptr(), targets.data_ptr(), sb, ss, b, s, h, w, out.data_ptr(),
-                                                 aux.data_ptr(), L.stream()), "ds_reprojection_loss_fwd")
-        ctx.save_for_backward(preds, targets, aux)
-        ctx.strides = (sb, ss)
-        ctx.mark_non_differentiable(aux)
-        return out, aux
+        saved, ctx.strides, out = reprojection_loss_impl(preds, targets, shared_target)
+        ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(saved[2])
+        return out, saved[2]
 
     @staticmethod
     def backward(ctx, g_out, _g_aux):
         preds, targets, aux = ctx.saved_tensors
         if ctx.needs_input_grad[1]:
             raise RuntimeError("reprojection_loss: gradient w.r.t. targets is not implemented")
-        b, s, c, h, w = preds.shape
-        sb, ss = ctx.strides
-        g_out = L.dev_f32(g_out, "grad")
-        gp = torch.empty_like(preds)
-        L.check(L.lib().ds_reprojection_loss_bwd(preds.data_ptr(), targets.data_ptr(), sb, ss, g_out.data_ptr(),
-                                                 aux.data_ptr(), b, s, h, w, gp.data_ptr(), L.stream()),
-                "ds_reprojection_loss_bwd")
-        return gp, None, None
+        return reprojection_loss_bwd_impl(preds, targets, aux, ctx.strides, g_out), None, None
 
 
 def reprojection_loss(preds, targets, shared_target: bool):
@@ -413,6 +442,36 @@ class _TrainStep(torch.autograd.Function):
         return None, None, gp.reshape(ctx.pose_shape), gd, None, None, None
 
 
+def train_step_fwdbwd_impl(K, Kinv, pose, depth, src, target, smooth_scale: float):
+    """ONE C call (ds_train_step_fwdbwd) -> (total, sums, reg, warped, out, idt, aux, g_depth, g_pose (B*S,3,4))."""
+    depth, src, target = L.dev_f32(depth, "depth"), L.dev_f32(src, "src"), L.dev_f32(target, "target")
+    b, s, c, hs, ws = src.shape
+    h, w = target.shape[-2:]
+    n = b * s
+    if c != 3 or target.shape != (b, 3, h, w) or depth.numel() != n * h * w or (hs, ws) != (h, w):
+        raise RuntimeError(f"expected src (B,S,3,H,W), target (B,3,H,W), depth (B,S,1,H,W); got {tuple(src.shape)}, "
+                           f"{tuple(target.shape)}, {tuple(depth.shape)}")
+    K, Kinv, pose = _chk_cam(K, Kinv, pose.reshape(n, 3, 4), n)
+    L.same_device(depth, src, target, K, Kinv, pose)
+    dev, lib, st = src.device, L.lib(), L.stream()
+    f32 = dict(dtype=torch.float32, device=dev)
+    nb = lib.ds_train_step_fwdbwd_workspace_bytes(b, s, h, w)
+    wsb = L.workspace.get(nb, dev)
+    warped = torch.empty(b, s, 3, h, w, **f32)
+    # d loss / d warped stays inside the kernel for S <= 3; only the S = 4 path needs the (B,S,3,H,W) scratch
+    gw = torch.empty(b, s, 3, h, w, **f32) if s > 3 else None
+    out, idt = torch.empty(b, h, w, **f32), torch.empty(b, h, w, **f32)
+    aux = torch.empty(b, h, w, dtype=torch.uint8, device=dev)
+    sums, reg, total = torch.empty(b, 2, **f32), torch.empty(1, **f32), torch.empty((), **f32)
+    gd, gp = torch.empty_like(depth), torch.empty(n, 3, 4, **f32)
+    L.check(lib.ds_train_step_fwdbwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
+                                     target.data_ptr(), smooth_scale, b, s, h, w, warped.data_ptr(), out.data_ptr(),
+                                     idt.data_ptr(), aux.data_ptr(), sums.data_ptr(), reg.data_ptr(), total.data_ptr(),
+                                     L.ptr(gw), gd.data_ptr(), gp.data_ptr(), wsb.data_ptr(), nb, st),
+            "ds_train_step_fwdbwd")
+    return total, sums, reg, warped, out, idt, aux, gd, gp
+
+
 class _TrainStepEager(torch.autograd.Function):
     """The same step with its gradients formed in the forward call: ONE C call, ds_train_step_fwdbwd (the photometric step's
     three launches, the smoothness value and gradient from one kernel, a finalize that also forms total).  total is linear
@@ -420,32 +479,8 @@ class _TrainStepEager(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, K, Kinv, pose, depth, src, target, smooth_scale):
-        depth, src, target = L.dev_f32(depth, "depth"), L.dev_f32(src, "src"), L.dev_f32(target, "target")
-        b, s, c, hs, ws = src.shape
-        h, w = target.shape[-2:]
-        n = b * s
         ctx.pose_shape = pose.shape
-        if c != 3 or target.shape != (b, 3, h, w) or depth.numel() != n * h * w or (hs, ws) != (h, w):
-            raise RuntimeError(f"expected src (B,S,3,H,W), target (B,3,H,W), depth (B,S,1,H,W); got {tuple(src.shape)}, "
-                               f"{tuple(target.shape)}, {tuple(depth.shape)}")
-        K, Kinv, pose = _chk_cam(K, Kinv, pose.reshape(n, 3, 4), n)
-        L.same_device(depth, src, target, K, Kinv, pose)
-        dev, lib, st = src.device, L.lib(), L.stream()
-        f32 = dict(dtype=torch.float32, device=dev)
-        nb = lib.ds_train_step_fwdbwd_workspace_bytes(b, s, h, w)
-        wsb = L.workspace.get(nb, dev)
-        warped = torch.empty(b, s, 3, h, w, **f32)
-        # d loss / d warped stays inside the kernel for S <= 3; only the S = 4 path needs the (B,S,3,H,W) scratch
-        gw = torch.empty(b, s, 3, h, w, **f32) if s > 3 else None
-        out, idt = torch.empty(b, h, w, **f32), torch.empty(b, h, w, **f32)
-        aux = torch.empty(b, h, w, dtype=torch.uint8, device=dev)
-        sums, reg, total = torch.empty(b, 2, **f32), torch.empty(1, **f32), torch.empty((), **f32)
-        gd, gp = torch.empty_like(depth), torch.empty(n, 3, 4, **f32)
-        L.check(lib.ds_train_step_fwdbwd(K.data_ptr(), Kinv.data_ptr(), pose.data_ptr(), depth.data_ptr(), src.data_ptr(),
-                                         target.data_ptr(), smooth_scale, b, s, h, w, warped.data_ptr(), out.data_ptr(),
-                                         idt.data_ptr(), aux.data_ptr(), sums.data_ptr(), reg.data_ptr(), total.data_ptr(),
-                                         L.ptr(gw), gd.data_ptr(), gp.data_ptr(), wsb.data_ptr(), nb, st),
-                "ds_train_step_fwdbwd")
+        total, sums, reg, warped, out, idt, aux, gd, gp = train_step_fwdbwd_impl(K, Kinv, pose, depth, src, target, smooth_scale)
         ctx.save_for_backward(gd, gp)
         ctx.mark_non_differentiable(sums, reg, warped, out, idt, aux)
         ctx.set_materialize_grads(False)
