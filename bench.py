@@ -66,6 +66,11 @@ def step_alg_bytes_per_target_px(S, C=3, image_grad=False):
     return 4 * (S + 2 * C * S + C + 2) + 4 * (2 * S + 2 * C * S + C + 2) + (4 * C * S if image_grad else 0)
 
 
+# pose vectors of the synthetic batch are N(0, POSE_SIGMA^2) per component; the environment variable is for traffic
+# diagnostics only (0 = identity warp: every gather lands on the pixel's own texel) and shows up in config.pose_sigma
+POSE_SIGMA = float(os.environ.get("DS_BENCH_POSE_SIGMA", "0.01"))
+
+
 class Scale:
     """All device buffers of one (B,S,H,W) problem + the C-ABI calls of a step."""
 
@@ -78,7 +83,7 @@ class Scale:
         self.src = torch.rand(B, S, 3, H, W, generator=g).to(dev)
         self.tgt = torch.rand(B, 3, H, W, generator=g).to(dev)
         self.depth = (1 + 79 * torch.rand(B, S, H, W, generator=g)).to(dev)
-        vec = (0.01 * torch.randn(B * S, 6, generator=g)).to(dev)
+        vec = (POSE_SIGMA * torch.randn(B * S, 6, generator=g)).to(dev)
         self.pose = de.ops.pose_from_vec(vec).contiguous()
         K, Kinv = de.fused.intrinsics(W, H)
         self.K, self.Kinv = K.to(dev), Kinv.to(dev)
@@ -716,7 +721,8 @@ def main():
                                   ("three C-ABI calls per step (ds_resize_bilinear, ds_plane_sweep_depth_batch, ds_resize_bicubic)"
                                    if "sweep" in wl else "one C-ABI call per step (" +
                                    ("ds_loss_step_fwd: forward only" if wl.get("fwd_only") else "ds_loss_step_fwdbwd") + ")")),
-                       "parallelism": f"batch-sharded x{world}, no collective", "spin_up_s": args.spin_up},
+                       "parallelism": f"batch-sharded x{world}, no collective", "spin_up_s": args.spin_up,
+                       "pose_sigma": POSE_SIGMA},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(hbm_frac, 4), "traffic": traffic,
                          "alg_bytes_per_launch": sc0.alg_bytes[dom], "avg_ms": round(kern_ms[dom], 5),

@@ -137,6 +137,14 @@ __device__ __forceinline__ int buf_load_u8(rsrc_t r, unsigned lane_bytes, unsign
     return (int)__builtin_amdgcn_raw_buffer_load_b8(r, lane_bytes, uniform_bytes, 0);
 }
 
+// the same with the non-temporal bit (gfx940+: aux bit 1 = nt): data that is used once should not push re-used lines out of L2
+__device__ __forceinline__ float buf_load_f32_nt(rsrc_t r, unsigned lane_bytes, unsigned uniform_elems) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_bytes, uniform_elems * 4u, 2));
+}
+__device__ __forceinline__ void buf_store_f32_nt(float v, rsrc_t r, unsigned lane_bytes, unsigned uniform_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, lane_bytes, uniform_bytes, 2);
+}
+
 typedef float float2_t __attribute__((ext_vector_type(2)));
 // two adjacent floats at a 4-byte aligned address (gfx950 buffer loads need no natural alignment)
 __device__ __forceinline__ float2_t buf_load_f32x2(rsrc_t r, unsigned lane_bytes, unsigned uniform_bytes) {

@@ -18,7 +18,11 @@
 #ifndef DS_EXP
 #define DS_EXP 0   // experiments (scripts/build_exp.sh), forward kernel, bit mask: 1 = synthetic row values instead of
                    // global loads, 2 = no workgroup barriers, 8 = the loss workgroups of warp_idt_kernel do not warp (wrong
-                   // results; timing only)
+                   // results; timing only), 16 = non-temporal hint on the once-used traffic of warp_idt_kernel (target and
+                   // depth loads, warped stores), 32 = on the loads only
+#endif
+#ifndef DS_ROUNDS
+#define DS_ROUNDS 5   // launches with many more workgroups than fit at once: rounds of resident workgroups aimed for (pick_chunks)
 #endif
 #include "ds_common.h"
 #include "ds_warp_dev.h"
@@ -119,6 +123,15 @@ constexpr int kLdsRow = 68;  // 64 columns + left/right halo column (+2 pad)
 // light waves spread evenly over the four SIMDs.
 constexpr int kFwdWaves = 4;
 
+// warp_idt_kernel's traffic that no other workgroup reads again (see DS_EXP 16 / 32)
+__device__ __forceinline__ float ld_once(rsrc_t r, unsigned lane_bytes, unsigned uniform_elems) {
+    return (DS_EXP & 48) ? buf_load_f32_nt(r, lane_bytes, uniform_elems) : buf_load_f32(r, lane_bytes, uniform_elems);
+}
+__device__ __forceinline__ void st_once(float v, rsrc_t r, unsigned lane_bytes, unsigned uniform_bytes) {
+    if (DS_EXP & 16) buf_store_f32_nt(v, r, lane_bytes, uniform_bytes);
+    else buf_store_f32(v, r, lane_bytes, uniform_bytes);
+}
+
 // bid / nblk: this workgroup's index in the list of the launch's loss workgroups (the block index in a plain launch)
 // EW: the E wave -- idle nine tenths of the time -- also runs ds_warp_fwd for the band's rows (Q: the warp's arguments),
 // software-pipelined around the slab barriers so that no gather is waited for: a unit = 2 rows x S sources is projected
@@ -163,7 +176,7 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
                 const int row = min(y0 + u * UR + i, H - 1);
 #pragma unroll
                 for (int s = 0; s < SW; ++s)
-                    dnx[i][s] = buf_load_f32(make_rsrc(Q->depth + (size_t)(b * S + s) * HW), xb, (unsigned)(row * W));
+                    dnx[i][s] = ld_once(make_rsrc(Q->depth + (size_t)(b * S + s) * HW), xb, (unsigned)(row * W));
             }
         };
         auto issue_unit = [&](int u) {
@@ -201,7 +214,7 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
                         acc = fmaf(top[i][s][c3].y, wgt[i][s][1], acc);
                         acc = fmaf(bot[i][s][c3].x, wgt[i][s][2], acc);
                         acc = fmaf(bot[i][s][c3].y, wgt[i][s][3], acc);
-                        if (lane_out) buf_store_f32(acc, op, (unsigned)col * 4u, (c3 * uHW + (unsigned)(row * W)) * 4u);
+                        if (lane_out) st_once(acc, op, (unsigned)col * 4u, (c3 * uHW + (unsigned)(row * W)) * 4u);
                     }
                 }
             }
@@ -311,8 +324,8 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
         (void)ro;
         return;
 #endif
-        v[0] = buf_load_f32(tp, cl, c * uHW + ro);
-        h[0] = buf_load_f32(tp, ch, c * uHW + ro);
+        v[0] = EW ? ld_once(tp, cl, c * uHW + ro) : buf_load_f32(tp, cl, c * uHW + ro);
+        h[0] = EW ? ld_once(tp, ch, c * uHW + ro) : buf_load_f32(tp, ch, c * uHW + ro);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             v[1 + s] = buf_load_f32(pp, cl, (s * 3 + c) * uHW + ro);
@@ -364,7 +377,7 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
     const int xcw = min(col, W - 1);
     if (EWC) {
         load_cam(camw, Q->K, Q->Kinv, Q->pose + 12 * (b * S + s1));
-        if (y0 + c < yend) wdn = buf_load_f32(make_rsrc(Q->depth + (size_t)(b * S + s1) * HW), (unsigned)xcw * 4u, (unsigned)((y0 + c) * W));
+        if (y0 + c < yend) wdn = ld_once(make_rsrc(Q->depth + (size_t)(b * S + s1) * HW), (unsigned)xcw * 4u, (unsigned)((y0 + c) * W));
     }
     auto warp_finish = [&]() {
         const rsrc_t op = make_rsrc(Q->warped + (size_t)(b * S + s1) * 3 * HW);
@@ -374,7 +387,7 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
             acc = fmaf(wtop[c3].y, wwg[1], acc);
             acc = fmaf(wbot[c3].x, wwg[2], acc);
             acc = fmaf(wbot[c3].y, wwg[3], acc);
-            if (col < W) buf_store_f32(acc, op, (unsigned)col * 4u, (c3 * uHW + (unsigned)(wpend * W)) * 4u);
+            if (col < W) st_once(acc, op, (unsigned)col * 4u, (c3 * uHW + (unsigned)(wpend * W)) * 4u);
         }
     };
     auto warp_issue = [&](int row) {
@@ -392,7 +405,7 @@ __device__ __forceinline__ void photo_fwd_body(const PhotoFwdParams& P, int bid,
         wwg[0] = tpw.wa_t; wwg[1] = tpw.wb_t; wwg[2] = tpw.wa_b; wwg[3] = tpw.wb_b;
         wpend = row;
         if (row + 3 < yend)
-            wdn = buf_load_f32(make_rsrc(Q->depth + (size_t)(b * S + s1) * HW), (unsigned)xcw * 4u, (unsigned)((row + 3) * W));
+            wdn = ld_once(make_rsrc(Q->depth + (size_t)(b * S + s1) * HW), (unsigned)xcw * 4u, (unsigned)((row + 3) * W));
     };
 
     float pend[NP], pendh[NP], cL[NP], cC[NP], cR[NP];
@@ -1564,7 +1577,7 @@ inline bool fwd_uses_lds(int S, bool idt) { return (idt ? 2 * S : S) <= 6; }
 // short chunk repeats cost nothing there (24x80 x 12 targets: 27 -> 9 us for the fused loss kernel).
 inline long long pick_chunks(long long per_chunk, long long capacity, int H, int min_rows) {
     int max_nby = H / min_rows > 1 ? H / min_rows : 1;
-    long long nby = (8 * capacity + per_chunk - 1) / per_chunk;   // about eight rounds
+    long long nby = (DS_ROUNDS * capacity + per_chunk - 1) / per_chunk;   // about DS_ROUNDS rounds
     if (nby <= max_nby) return nby;
     if (per_chunk * max_nby < capacity) {
         max_nby = H / 4 > 1 ? H / 4 : 1;
