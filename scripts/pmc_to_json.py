@@ -14,7 +14,8 @@ tag = sys.argv[1]
 KERNELS = {"warp_identity": "warp_idt_kernel<2, true>", "loss_fb_warp_bwd": "photo_fb_kernel<2, true>",
            "loss_fb": "photo_fb_kernel<2, false>", "warp_bwd": "warp_bwd_kernel<3, false, 8>",
            "warp_fwd": "warp_fwd_kernel<3>", "loss_fwd": "photo_fwd_kernel<2, true>", "loss_bwd": "photo_bwd_kernel<2, true>",
-           "metrics": "metrics_kernel"}
+           "metrics": "metrics_kernel", "plane_sweep": "plane_sweep_depth_kernel<3>", "resize_bilinear": "resize_bilinear_kernel",
+           "resize_bicubic": "resize_bicubic_kernel"}
 
 
 def read(path):
@@ -32,7 +33,7 @@ def read(path):
 
 
 res = {"_comment": __doc__.strip().split("\n", 2)[2].strip() + f"  Source: gpurun_out/pmc_{tag}_* (copies under profiles/)."}
-for wl in ("b12_s2_192x640_fwdbwd", "b64_s2_320x1024_fwdbwd"):
+for wl in ("b12_s2_192x640_fwdbwd", "b64_s2_320x1024_fwdbwd", "b12_s2_sweep80_96x320"):
     f, w, q, q2 = [read(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{c}_{wl}.txt"))
                    for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ1", "SQ2")]
     d = {}
@@ -53,13 +54,14 @@ for wl in ("b12_s2_192x640_fwdbwd", "b64_s2_320x1024_fwdbwd"):
 # config 3: the finest level's launches, from the single-level passes with --image-grad
 f, w, q = [read(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{c}_imggrad.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ1")]
 d = {}
-for name, kern in (("warp_identity", "warp_idt_kernel<2, true>"), ("loss_fb", "photo_fb_kernel<2, false>"),
-                   ("warp_bwd", "warp_bwd_kernel<3, true, 8>")):
+# (the warp backward with the image gradient is two launches: the backward itself with its staging, then the reducer)
+for name, kerns in (("warp_identity", ("warp_idt_kernel<2, true>",)), ("loss_fb", ("photo_fb_kernel<2, false>",)),
+                    ("warp_bwd", ("warp_bwd_kernel<3, true, 8>", "img_reduce_kernel"))):
     e = {}
-    if kern in f and kern in w:
-        e["hbm_bytes"] = int((2 * f[kern]["FETCH_SIZE"] + w[kern]["WRITE_SIZE"]) * 1024)
-    if kern in q and "SQ_INSTS_VALU" in q[kern]:
-        e["valu_wave_insts"] = int(q[kern]["SQ_INSTS_VALU"])
+    if all(k in f and k in w for k in kerns):
+        e["hbm_bytes"] = int(sum(2 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"] for k in kerns) * 1024)
+    if all(k in q and "SQ_INSTS_VALU" in q[k] for k in kerns):
+        e["valu_wave_insts"] = int(sum(q[k]["SQ_INSTS_VALU"] for k in kerns))
     if e:
         d[name] = e
 if d:

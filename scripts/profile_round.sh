@@ -10,8 +10,9 @@ python3 -c "import torch" || exit 1
 timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 > $out/bench_b12.json 2> $out/bench_b12.err || exit 1
 timeout -k 10 300 python3 bench.py --steps 50 --warmup 10 --workload b64_s2_320x1024_fwdbwd --no-cpu > $out/bench_hires.json 2> $out/bench_hires.err || exit 1
 timeout -k 10 300 python3 bench.py --steps 100 --warmup 10 --workload b12_s2_192x640_pyramid4_fwdbwd --no-cpu > $out/bench_pyramid.json 2> $out/bench_pyramid.err || exit 1
-timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $out/stats_b12 -o p --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu --cold-steps 0 --pipelined 0 --spin-up 0 > $out/stats_b12.log 2>&1 || exit 1
-timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $out/stats_hires -o p --output-format csv -- python3 bench.py --steps 20 --warmup 5 --workload b64_s2_320x1024_fwdbwd --no-cpu --cold-steps 0 --pipelined 0 --spin-up 0 > $out/stats_hires.log 2>&1 || exit 1
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $out/stats_b12 -o p --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu --no-also --cold-steps 0 --pipelined 0 --spin-up 0 > $out/stats_b12.log 2>&1 || exit 1
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $out/stats_hires -o p --output-format csv -- python3 bench.py --steps 20 --warmup 5 --workload b64_s2_320x1024_fwdbwd --no-cpu --no-also --cold-steps 0 --pipelined 0 --spin-up 0 > $out/stats_hires.log 2>&1 || exit 1
+find $out -name "*kernel_trace.csv" -delete   # per-dispatch traces are large; the stats files stay
 [ "${2:-}" = quick ] && { echo done-quick; exit 0; }
 for wl in b12_s2_192x640_fwdbwd b64_s2_320x1024_fwdbwd; do
   for c in FETCH_SIZE WRITE_SIZE; do
