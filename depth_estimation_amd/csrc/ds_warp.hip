@@ -222,21 +222,29 @@ constexpr int kSegFloats = 3 * 66;  // one slot: 3 channels x (outer column, 64 
 //   hdrA[tile] = { rbase: source row of slot 0,  mask: filled slots (bit 31: the point list is not empty),
 //                  cbmin, cbmax: range of cb[] over the filled slots }
 //   hdrB[tile] = { npt: entries of the point list,  prmin, prmax: the rows they span,  - }
-//   cb[tile][kCbStride]: [k] = source column of slot k's first OWNED column (entry 1 of its 66); [16], [17] = the range of
+//   hdrC[tile] = 16 signed bytes: [k] = slot k's window offset cb (its first OWNED column, entry 1 of its 66, is source
+//                  column 64 * bx + cb; a window further than 127 columns from its pixels gets no slot)
+//   (round 3 first had cb[tile][18] ints read by dependent loads: [k] = column of slot k, [16], [17] = the range of
 //                  the points' left columns
-constexpr int kCbStride = kSegRows + 2;
-struct PtEntry {                    // the two texels (col, col+1) of source row `row`; 32 bytes
-    int row, col;
-    float v[3][2];
+// A point = one pixel's whole bilinear tap, 24 bytes: the reducer forms the four weights from the two fractions exactly as
+// make_tap does (sy * ex, sy * wx, ny * ex, ny * wx with ex = 1 - wx, sy = 1 - ny) and the 12 products g[c] * w itself, so the
+// sums get the bits they had when pass 1 formed the products (32 bytes per texel ROW, two entries per pixel: 189 MB of
+// stores per launch with bench.py's per-pixel random depth, 39 of pass 1's 69 us).  A tap on the last column has
+// (wx, col) = (1, Ws-2) instead of make_tap's shifted pair: the same texels and products.  A single value for one texel
+// (a window row without a slot, the sum of a run) is the entry (value, wx = 0, ny = 0): weight 1 on (row, col), 0 elsewhere.
+struct PtEntry {
+    unsigned rc;                    // row << 16 | (col + 1): row <= 32767, col in [-1, 65534] (checked on the host)
+    float g[3];
+    float wx, ny;
 };
 struct ImgStage {                   // into the caller's workspace (ds_warp_bwd_image_workspace_bytes)
     int4* hdrA;                     // [N][nwy][nbx]
     int4* hdrB;
-    int* cb;                        // [N][nwy][nbx][kCbStride]
+    int4* hdrC;
     float* seg;                     // [N][nwy][nbx][kSegRows][kSegFloats]
     PtEntry* pt;                    // [N][nwy][nbx][pts_per_tile]
     int nwy;                        // tile rows per image = ceil(H / ROWS)
-    int pts_per_tile;               // worst case: every pixel a point (2 entries) or every finished row misplaced (66 + 2)
+    int pts_per_tile;               // worst case per pixel row: three finished window rows without a slot (66 each) + 12 misfits
 };
 
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -304,17 +312,15 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
     int prmin = 0x7fffffff, prmax = -0x7fffffff - 1, pcmin = 0x7fffffff, pcmax = -0x7fffffff - 1;   // per lane
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     // append one point per lane with `has` to the tile's list, in lane order
-    auto push_point = [&](bool has, int row, int pcol, float a0, float a1, float a2, float b0, float b1, float b2) {
+    auto push_point = [&](bool has, int row, int pcol, float g0, float g1, float g2, float wx, float ny) {
         const unsigned long long m = __ballot(has);
         if (m == 0) return;   // uniform
         if (has) {
             PtEntry* e = st.pt + tix * st.pts_per_tile + npt + __popcll(m & lt_mask);
-            e->row = row;
-            e->col = pcol;
-            e->v[0][0] = a0; e->v[0][1] = b0;
-            e->v[1][0] = a1; e->v[1][1] = b1;
-            e->v[2][0] = a2; e->v[2][1] = b2;
-            prmin = min(prmin, row); prmax = max(prmax, row);
+            e->rc = ((unsigned)row << 16) | (unsigned)(pcol + 1);
+            e->g[0] = g0; e->g[1] = g1; e->g[2] = g2;
+            e->wx = wx; e->ny = ny;
+            prmin = min(prmin, row); prmax = max(prmax, row + 1);   // (an entry reaches the row below as well)
             pcmin = min(pcmin, pcol); pcmax = max(pcmax, pcol);
         }
         npt += __popcll(m);
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
         if (IMG && r >= 0 && r < G.Hs && __ballot(nz || enz) != 0) {   // uniform
             if (!have_base) { rbase = r - 2; have_base = true; }
             const int k = r - rbase;
-            if (k >= 0 && k < kSegRows && !((smask >> k) & 1u)) {
+            if (k >= 0 && k < kSegRows && !((smask >> k) & 1u) && win.cb >= -128 && win.cb <= 127) {
                 float* p = st.seg + (tix * kSegRows + k) * kSegFloats;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) p[c * 66 + 1 + lane] = win.a[c][0];
@@ -336,15 +342,15 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
                     for (int c = 0; c < 3; ++c) p[c * 66 + (lane == 0 ? 0 : 65)] = win.e[c][0];
                 }
                 const int cb0 = bx * 64 + win.cb;
-                if (lane == 0) st.cb[tix * kCbStride + k] = cb0;
+                if (lane == 0) reinterpret_cast<signed char*>(st.hdrC)[tix * 16 + k] = (signed char)win.cb;
                 cbmin = min(cbmin, cb0);
                 cbmax = max(cbmax, cb0);
                 smask |= 1u << k;
             } else {
                 // no slot for this row: it leaves as points (a lane's own column, then the two outer columns)
                 const int col = x + win.cb;
-                push_point(nz, r, col, win.a[0][0], win.a[1][0], win.a[2][0], 0.f, 0.f, 0.f);
-                push_point(enz, r, col + (lane == 0 ? -1 : 1), win.e[0][0], win.e[1][0], win.e[2][0], 0.f, 0.f, 0.f);
+                push_point(nz, r, col, win.a[0][0], win.a[1][0], win.a[2][0], 0.f, 0.f);
+                push_point(enz, r, col + (lane == 0 ? -1 : 1), win.e[0][0], win.e[1][0], win.e[2][0], 0.f, 0.f);
             }
         }
 #pragma unroll
@@ -504,33 +510,39 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
                 }
             }
             {
-                // points: the top and the bottom texel row of every pixel that did not go through the window
+                // points: every pixel that did not go through the window leaves its tap (PtEntry)
                 const bool any = direct && (g[0] != 0.0f || g[1] != 0.0f || g[2] != 0.0f);
                 // A run of neighbouring lanes on ONE tap (pixels beyond the left or right border all clamp to the border
                 // column; a far plane collapses onto a texel) would reach the reducer as that many entries for one texel,
-                // which one of its threads then adds one after the other (chunk 0 of a forward-moving camera: 640 k cycles
-                // for a wave against a median of 27 k).  Such runs are summed here first, by a segmented scan over the
-                // lanes -- a fixed tree, so still the same bits every run -- and only a run's last lane leaves an entry.
+                // which it then adds one after the other (chunk 0 of a forward-moving camera: 640 k cycles for a wave
+                // against a median of 27 k).  Runs of four lanes or more are summed here first, by a segmented scan over
+                // the lanes -- a fixed tree, so still the same bits every run -- and the run's last lane leaves the four
+                // sums as single values.
                 // (the three shuffles with every lane active: a lane switched off by a short-circuit reads as 0)
                 const bool prev_any = __shfl_up((int)any, 1, 64) != 0;
                 const int prev_y0 = __shfl_up(t.y0, 1, 64), prev_xl = __shfl_up(t.xl, 1, 64);
                 const bool cont = any && lane > 0 && prev_any && prev_y0 == t.y0 && prev_xl == t.xl;
                 const unsigned long long cm = __ballot(cont);
-                const bool scan = __popcll(cm) >= kMinRunLanes;   // uniform
+                const bool scan = __popcll(cm) >= kMinRunLanes - 1;   // uniform: a run of kMinRunLanes may exist
+                bool in_long = false, last = true;
                 int head = lane;
-                bool last = true;
                 if (scan) {
                     head = 63 - __builtin_clzll(~cm & (lt_mask | (1ull << lane)));   // first lane of this lane's run
-                    last = lane == 63 || !((cm >> (lane + 1)) & 1ull);
+                    const unsigned long long ends = ~(cm >> 1) | (1ull << 63);        // lanes whose successor does not continue
+                    const int end = lane + __builtin_ctzll(ends >> lane);
+                    last = end == lane;
+                    in_long = any && end - head + 1 >= kMinRunLanes;
                 }
-                auto row_points = [&](int row, float wa, float wb) {
-                    float v[6];
+                const float wxe = t.shift ? 1.0f : t.wx;   // (shift: make_tap's pair starts at Ws-2 with the weight on its right texel)
+                push_point(any && !in_long, t.y0, t.xl, g[0], g[1], g[2], wxe, t.ny);
+                if (scan && __ballot(in_long) != 0) {   // uniform
+                    auto run_sums = [&](int row, float wa, float wb) {
+                        float v[6];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        v[2 * c] = any ? g[c] * wa : 0.f;
-                        v[2 * c + 1] = any ? g[c] * wb : 0.f;
-                    }
-                    if (scan) {
+                        for (int c = 0; c < 3; ++c) {
+                            v[2 * c] = in_long ? g[c] * wa : 0.f;
+                            v[2 * c + 1] = in_long ? g[c] * wb : 0.f;
+                        }
 #pragma unroll
                         for (int o = 1; o < 64; o <<= 1) {
                             const bool take = lane - o >= head;
@@ -540,14 +552,13 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
                                 v[q] += take ? u : 0.f;
                             }
                         }
-                    }
-                    bool nzv = false;
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) nzv = nzv || v[q] != 0.0f;
-                    push_point(any && last && nzv, row, t.xl, v[0], v[2], v[4], v[1], v[3], v[5]);
-                };
-                row_points(t.y0, t.wa_t, t.wb_t);
-                row_points(t.y1, t.wa_b, t.wb_b);
+                        const bool lead = in_long && last;
+                        push_point(lead && (v[0] != 0.0f || v[2] != 0.0f || v[4] != 0.0f), row, t.xl, v[0], v[2], v[4], 0.f, 0.f);
+                        push_point(lead && (v[1] != 0.0f || v[3] != 0.0f || v[5] != 0.0f), row, t.xl + 1, v[1], v[3], v[5], 0.f, 0.f);
+                    };
+                    run_sums(t.y0, t.wa_t, t.wb_t);
+                    run_sums(t.y1, t.wa_b, t.wb_b);
+                }
             }
         } else if (g_src && x < G.W) {  // generic channel count: float atomics straight to memory
             Samp s;
@@ -588,9 +599,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
         pcmin = wave_min_i(pcmin); pcmax = wave_max_i(pcmax);
         if (lane == 0) {
             st.hdrA[tix] = make_int4(rbase, (int)(smask | (npt > 0 ? 0x80000000u : 0u)), cbmin, cbmax);
-            st.hdrB[tix] = make_int4(npt, prmin, prmax, 0);
-            st.cb[tix * kCbStride + kSegRows] = pcmin;
-            st.cb[tix * kCbStride + kSegRows + 1] = pcmax;
+            st.hdrB[tix] = make_int4(npt, prmin, prmax, npt > 0 ? ((pcmin + 1) << 16) | (pcmax + 1) : 0);
         }
     }
     block_reduce12(gM, partials + ((size_t)n * gridDim.x + blockIdx.x) * 12, lds);
@@ -606,19 +615,20 @@ constexpr int kRedRows = DS_RED_ROWS;   // source rows per wave of the reducer
 constexpr int kMaxCand = 12;            // segments per (row, 64 columns) kept from the scan (2-4 for a smooth warp; max 6 seen)
 constexpr int kCandFirst = 3;           // of those, fetched for all rows at once
 constexpr int kPtBatches = 4;           // point-list batches (64 entries each) whose loads are in flight together
-// The reducer is bound by the latency of its dependent loads (tile records -> a slot's first column -> the slot's values; a
-// point list, batch after batch), not by bytes: one source row per wave (46 k short waves at 12 x 2 x 192 x 640) took 80 us,
+// The reducer is bound by the latency of its dependent loads (tile records -> the slot's values; a point list, batch after
+// batch), not by bytes: one source row per wave (46 k short waves at 12 x 2 x 192 x 640) took 80 us,
 // eight rows per wave handled one after the other 174 us.  So a wave takes 64 columns x kRedRows rows and works in phases that
 // each keep all their loads in flight:
 //   (1) the records of all tiles of its image, 256 at a time: every lane whose tile holds a segment for one of the rows
 //       leaves (tile, slot) in the row's candidate list in LDS (position from a ballot prefix: tile order);
 //   (P) the point lists whose row and column ranges meet the wave's texels, kPtBatches x 64 entries at a time, added to the
 //       wave's texels in LDS (below);
-//   (2) lane f takes entry f of the lists and loads its slot's first column; then the values of the first kCandFirst
+//   (2) lane f takes entry f of the lists (tile, slot, first column: all from the records); then the values of the first kCandFirst
 //       candidates of ALL rows are requested together and added in list order (further candidates, rare, row by row).
 __global__ __launch_bounds__(kThreads) void img_reduce_kernel(ImgStage st, int nbx, int Hs, int Ws, float* __restrict__ g_src) {
     constexpr int kFlat = kRedRows * kMaxCand, kE = (kFlat + 63) / 64;
     __shared__ int lds_tk[kThreads / 64][kFlat];                // (tile << 4) | slot, row i's list at i * kMaxCand
+    __shared__ int lds_cb[kThreads / 64][kFlat];                // the slot's first owned column
     __shared__ float4 lds_pt[kThreads / 64][kRedRows][64];      // the wave's texels: what the points add (x, y, z) and, in
                                                                 // w, the texel's bidding word (below)
     const int ngroups = (Hs + kRedRows - 1) / kRedRows;
@@ -630,11 +640,11 @@ __global__ __launch_bounds__(kThreads) void img_reduce_kernel(ImgStage st, int n
     const long long t_start = (DS_IMG_EXP & 32) ? (long long)__builtin_amdgcn_s_memtime() : 0;
     const int4* hdrA = st.hdrA + (size_t)n * T;
     const int4* hdrB = st.hdrB + (size_t)n * T;
-    const int* cbn = st.cb + (size_t)n * T * kCbStride;
+    const int4* hdrC = st.hdrC + (size_t)n * T;
     const float* segn = st.seg + (size_t)n * T * kSegRows * kSegFloats;
     // buffer loads (descriptor in scalar registers + one 32-bit offset per lane) for everything that is fetched in bulk:
     // with 64-bit addresses the 36 value loads of phase 2 alone held 72 registers and the kernel came to 254 + 52
-    const rsrc_t hA = make_rsrc(hdrA), cbr = make_rsrc(cbn), sgr = make_rsrc(segn);
+    const rsrc_t hA = make_rsrc(hdrA), hC = make_rsrc(hdrC), sgr = make_rsrc(segn);
     const rsrc_t ptr_ = make_rsrc(st.pt + (size_t)n * T * st.pts_per_tile);
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     float acc[kRedRows][3];
@@ -649,11 +659,13 @@ __global__ __launch_bounds__(kThreads) void img_reduce_kernel(ImgStage st, int n
     }
     constexpr int kU = 4;   // tile records looked at per lane and round: their loads are in flight together
     for (int base = 0; base < T; base += 64 * kU) {
-        int4 A[kU];
+        int4 A[kU], Cq[kU];
         // unconditional loads from clamped indices (a predicated load becomes a branch and a wait: the kU loads would go out
         // one after the other), lanes beyond the last tile get an empty record afterwards
 #pragma unroll
         for (int u = 0; u < kU; ++u) A[u] = buf_load_i32x4(hA, (unsigned)min(base + u * 64 + lane, T - 1) * 16u, 0u);   // rbase, mask, cbmin, cbmax
+#pragma unroll
+        for (int u = 0; u < kU; ++u) Cq[u] = buf_load_i32x4(hC, (unsigned)min(base + u * 64 + lane, T - 1) * 16u, 0u);  // the slots' offsets
 #pragma unroll
         for (int u = 0; u < kU; ++u)
             if (base + u * 64 + lane >= T) A[u] = make_int4(0, 0, 0, 0);
@@ -673,7 +685,12 @@ __global__ __launch_bounds__(kThreads) void img_reduce_kernel(ImgStage st, int n
                 const unsigned long long m = __ballot(c);
                 if (m == 0) continue;   // uniform
                 const int pos = cnt[i] + __popcll(m & lt_mask);
-                if (c && pos < kMaxCand) lds_tk[wave][i * kMaxCand + pos] = (t << 4) | (klo + i);
+                if (c && pos < kMaxCand) {
+                    const int k = klo + i;
+                    const int word = k < 8 ? (k < 4 ? Cq[u].x : Cq[u].y) : (k < 12 ? Cq[u].z : Cq[u].w);
+                    lds_tk[wave][i * kMaxCand + pos] = (t << 4) | k;
+                    lds_cb[wave][i * kMaxCand + pos] = (t % nbx) * 64 + ((word << (24 - 8 * (k & 3))) >> 24);   // sign-extended byte k
+                }
                 cnt[i] += __popcll(m);
             }
         }
@@ -687,7 +704,9 @@ __global__ __launch_bounds__(kThreads) void img_reduce_kernel(ImgStage st, int n
             for (int u = 0; u < kU; ++u) Bq[u] = buf_load_i32x4(hB, (unsigned)min(base + u * 64 + lane, T - 1) * 16u, 0u);   // npt, prmin, prmax, -
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                pmask[u] = __ballot(A[u].y < 0 && Bq[u].x > 0 && Bq[u].y <= r0 + kRedRows - 1 && r0 <= Bq[u].z);
+                // (w: the columns the list's taps start in, (min + 1) << 16 | (max + 1); a tap reaches one column further)
+                pmask[u] = __ballot(A[u].y < 0 && Bq[u].x > 0 && Bq[u].y <= r0 + kRedRows - 1 && r0 <= Bq[u].z &&
+                                    (Bq[u].w >> 16) - 1 <= c0 + 63 && (Bq[u].w & 0xffff) >= c0);
                 nptu[u] = Bq[u].x;
             }
         }
@@ -709,65 +728,88 @@ __global__ __launch_bounds__(kThreads) void img_reduce_kernel(ImgStage st, int n
                 const int m = __builtin_ctzll(pm);
                 pm &= pm - 1;
                 const int t = tb + m;
-                if (cbn[t * kCbStride + kSegRows] > c0 + 63 || cbn[t * kCbStride + kSegRows + 1] + 1 < c0) continue;   // uniform
                 const int npts = __builtin_amdgcn_readlane(nptv, m);
                 if (DS_IMG_EXP & 32) { dg_tiles += 1; dg_pts += npts; }
-                const unsigned pl = (unsigned)t * (unsigned)st.pts_per_tile * 32u;   // this tile's list inside the image's
+                const unsigned pl = (unsigned)t * (unsigned)st.pts_per_tile * (unsigned)sizeof(PtEntry);   // this tile's list inside the image's
                 for (int pb = 0; pb < npts; pb += 64 * kPtBatches) {
-                    int4 ea[kPtBatches], eb[kPtBatches];   // whole entries, from clamped indices
+                    int4 ea[kPtBatches];       // whole entries, from clamped indices: rc, g[0..2]
+                    float2_t eb[kPtBatches];   // wx, ny
 #pragma unroll
                     for (int q = 0; q < kPtBatches; ++q) {
-                        const int e = min(pb + q * 64 + lane, npts - 1);
-                        ea[q] = buf_load_i32x4(ptr_, (unsigned)e * 32u, pl);          // row, col, v[0][0], v[0][1]
-                        eb[q] = buf_load_i32x4(ptr_, (unsigned)e * 32u, pl + 16u);    // v[1][0], v[1][1], v[2][0], v[2][1]
+                        const unsigned eo = (unsigned)min(pb + q * 64 + lane, npts - 1) * (unsigned)sizeof(PtEntry);
+                        ea[q] = buf_load_i32x4(ptr_, eo, pl);
+                        eb[q] = buf_load_f32x2(ptr_, eo, pl + 16u);
                     }
 #pragma unroll
                     for (int q = 0; q < kPtBatches; ++q) {
-                        const int pr = ea[q].x - r0, pc = ea[q].y;
-                        const bool hit = pb + q * 64 + lane < npts && pr >= 0 && pr < kRedRows && pc + 1 >= c0 && pc <= c0 + 63;
+                        const int pr = (int)((unsigned)ea[q].x >> 16) - r0, pc = (int)((unsigned)ea[q].x & 0xffffu) - 1;
+                        // the tap covers rows pr, pr + 1 and columns pc, pc + 1
+                        const bool hit = pb + q * 64 + lane < npts && pr + 1 >= 0 && pr < kRedRows && pc + 1 >= c0 && pc <= c0 + 63;
                         const unsigned long long hits = __ballot(hit);
                         if (DS_IMG_EXP & 32) dg_hits += __popcll(hits);
                         if (hits == 0) continue;   // uniform
-                        const float pv[6] = {__builtin_bit_cast(float, ea[q].z), __builtin_bit_cast(float, ea[q].w),
-                                             __builtin_bit_cast(float, eb[q].x), __builtin_bit_cast(float, eb[q].y),
-                                             __builtin_bit_cast(float, eb[q].z), __builtin_bit_cast(float, eb[q].w)};
+                        const float g0 = __builtin_bit_cast(float, ea[q].y), g1 = __builtin_bit_cast(float, ea[q].z),
+                                    g2 = __builtin_bit_cast(float, ea[q].w);
+                        const float wx = eb[q].x, ny = eb[q].y, ex = 1.0f - wx, sy = 1.0f - ny;   // as make_tap forms them
+                        const float wgt[4] = {sy * ex, sy * wx, ny * ex, ny * wx};
                         if (!pt_used) {   // uniform: first entries for this wave's texels
                             pt_used = true;
 #pragma unroll
                             for (int i = 0; i < kRedRows; ++i) lds_pt[wave][i][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
                         }
-                        // The entries of this batch are added to the wave's texels in LDS, all lanes at once, first every
-                        // entry's left texel, then its right one.  Entries on the SAME texel have to be added one after
-                        // the other and in list order: each round the pending lanes bid for their texel with an integer
-                        // max (order-independent, unlike a float atomic) of (round, 63 - lane); the lowest lane of every
-                        // texel wins, adds with a plain read-modify-write, and leaves.  Rounds = the largest number of
-                        // entries on one texel (pass 1 has summed the long runs already).  One thread adding hit after
-                        // hit instead: 600 cycles a hit, 600 k cycles for the waves under an all-points tile.
+                        // The entries of this batch are added to the wave's texels in LDS, all lanes and all four corners of
+                        // their taps at once.  Additions to the SAME texel have to happen one after the other and in an order
+                        // that depends on nothing but the data: each round every pending (lane, corner) bids for its texel
+                        // with an integer max (order-independent, unlike a float atomic) of (round, corner, 63 - lane);
+                        // exactly one bid per texel survives, its owner adds with a plain read-modify-write and leaves, the
+                        // others bid again.  The four bids, the four reads and the writes of a round are each issued
+                        // together (a corner at a time: four times the LDS round trips; one thread adding hit after hit:
+                        // 600 cycles a hit).  Rounds = the largest number of additions to one texel in the batch: two for a
+                        // smooth warp (a tap's right texel is its neighbour's left one), more where pixels pile up (pass 1
+                        // has summed the long runs already).  A corner with weight 0 adds nothing and is left out.
+                        bool pending[4];
+                        float4* cell[4];
+                        unsigned anyp = 0;   // uniform
 #pragma unroll
-                        for (int side = 0; side < 2; ++side) {
-                            const int cx = pc + side - c0;
-                            bool pending = hit && cx >= 0 && cx <= 63;
-                            const int rr = min(max(pr, 0), kRedRows - 1), cc = min(max(cx, 0), 63);
-                            float4* cell = &lds_pt[wave][rr][cc];
-                            unsigned* tag = reinterpret_cast<unsigned*>(&lds_pt[wave][rr][cc].w);
-                            while (__ballot(pending)) {
-                                epoch += 1u;
-                                const unsigned bid = (epoch << 6) | (unsigned)(63 - lane);
-                                if (pending) __hip_atomic_fetch_max(tag, bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                                asm volatile("" ::: "memory");   // (the word is also cell->w: nothing kept across the bid)
-                                const float4 cur = *cell;        // the texel and its bidding word in one read
-                                const bool win = pending && __builtin_bit_cast(unsigned, cur.w) == bid;
-                                if (win) *cell = make_float4(cur.x + pv[side], cur.y + pv[2 + side], cur.z + pv[4 + side], cur.w);
-                                asm volatile("" ::: "memory");
-                                pending = pending && !win;
+                        for (int side = 0; side < 4; ++side) {
+                            const int ry = pr + (side >> 1), cx = pc + (side & 1) - c0;
+                            pending[side] = hit && wgt[side] != 0.0f && ry >= 0 && ry < kRedRows && cx >= 0 && cx <= 63;
+                            cell[side] = &lds_pt[wave][min(max(ry, 0), kRedRows - 1)][min(max(cx, 0), 63)];
+                            anyp |= __ballot(pending[side]) != 0 ? 1u << side : 0u;
+                        }
+                        while (anyp) {
+                            epoch += 1u;
+                            unsigned bid[4];
+#pragma unroll
+                            for (int side = 0; side < 4; ++side) {
+                                bid[side] = (epoch << 8) | ((unsigned)(3 - side) << 6) | (unsigned)(63 - lane);
+                                if (pending[side])
+                                    __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(&cell[side]->w), bid[side], __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
                             }
+                            asm volatile("" ::: "memory");   // (the bidding word is cell->w: nothing kept across the bids)
+                            float4 cur[4];
+#pragma unroll
+                            for (int side = 0; side < 4; ++side) cur[side] = *cell[side];   // the texel and its bidding word in one read
+                            asm volatile("" ::: "memory");
+                            anyp = 0;
+#pragma unroll
+                            for (int side = 0; side < 4; ++side) {
+                                const bool win = pending[side] && __builtin_bit_cast(unsigned, cur[side].w) == bid[side];
+                                const float w = wgt[side];
+                                // (winners own distinct texels, so none of these writes meets another's read above)
+                                if (win) *cell[side] = make_float4(cur[side].x + g0 * w, cur[side].y + g1 * w, cur[side].z + g2 * w, cur[side].w);
+                                pending[side] = pending[side] && !win;
+                                anyp |= __ballot(pending[side]) != 0 ? 1u << side : 0u;
+                            }
+                            asm volatile("" ::: "memory");
                         }
                     }
                 }
             }
         }
     }
-    // ---- phase 2: lane f holds entry f of the candidate lists and fetches the first column of its slot
+    // ---- phase 2: lane f holds entry f of the candidate lists
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     int tkf[kE], cbf[kE];
@@ -778,7 +820,7 @@ __global__ __launch_bounds__(kThreads) void img_reduce_kernel(ImgStage st, int n
 #pragma unroll
         for (int i = 0; i < kRedRows; ++i) ci = fi == i ? cnt[i] : ci;
         tkf[e] = fq < ci ? lds_tk[wave][f] : 0;      // (an unused entry reads tile 0, slot 0: memory that exists)
-        cbf[e] = __builtin_amdgcn_raw_buffer_load_b32(cbr, (unsigned)((tkf[e] >> 4) * kCbStride + (tkf[e] & 15)) * 4u, 0u, 0);
+        cbf[e] = fq < ci ? lds_cb[wave][f] : 0;
     }
     auto entry = [&](int f, int& tk, int& cb) {   // f is a compile-time constant wherever this is called
         tk = __builtin_amdgcn_readlane(tkf[f >> 6], f & 63);
@@ -872,7 +914,7 @@ __global__ __launch_bounds__(kThreads) void img_reduce_kernel(ImgStage st, int n
                     todo &= todo - 1;
                     if (seen++ < kMaxCand) continue;   // already added from the list
                     const int kk = __builtin_amdgcn_readlane(k, m);
-                    const int j = col - (cbn[(tb + m) * kCbStride + kk] - 1);
+                    const int j = col - (((tb + m) % nbx) * 64 + (int)reinterpret_cast<const signed char*>(hdrC)[(tb + m) * 16 + kk] - 1);
                     if (j >= 0 && j <= 65) {
                         const float* p = segn + ((size_t)(tb + m) * kSegRows + kk) * kSegFloats + j;
                         for (int ii = 0; ii < kRedRows; ++ii)
@@ -1053,13 +1095,13 @@ inline ImgLayout img_layout(int N, int H, int W) {
     ImgLayout L;
     const int rows = bwd_small(N, 3, H, W) ? kBwdRowsSmall : kBwdRows;
     L.nwy = (H + rows - 1) / rows;
-    L.pts_per_tile = 198 * (rows + 1);   // every finished window row misplaced (66 owned + outer columns, 3 per pixel row + 3)
-                                         // or every pixel a point (2 x 64 per row): the larger, per row
+    L.pts_per_tile = 210 * rows + 198;   // per pixel row: three finished window rows without a slot (66 entries each) and 12
+                                         // misfits, or 64 pixels as points; three more rows when the tile ends
     const size_t tiles = (size_t)N * L.nwy * ((W + 63) / 64);
     L.off_a = align256(ds_warp_bwd_workspace_bytes(N, H, W));
     L.off_b = align256(L.off_a + tiles * sizeof(int4));
     L.off_cb = align256(L.off_b + tiles * sizeof(int4));
-    L.off_seg = align256(L.off_cb + tiles * kCbStride * sizeof(int));
+    L.off_seg = align256(L.off_cb + tiles * sizeof(int4));
     L.off_pt = align256(L.off_seg + tiles * kSegRows * kSegFloats * sizeof(float));
     L.total = L.off_pt + tiles * L.pts_per_tile * sizeof(PtEntry);
     return L;
@@ -1188,6 +1230,14 @@ int ds::warp_bwd_partials(const float* K, const float* Kinv, const float* pose, 
         return DS_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < ds_warp_bwd_workspace_bytes(N, H, W)) return DS_ERR_WORKSPACE;
     const bool stage = g_src && C == 3;   // the image gradient without atomics (see ImgStage)
+    if (stage) {
+        // a point entry packs (row, column) into 32 bits; the reducer addresses an image's staging with 32-bit byte offsets
+        const ImgLayout L = img_layout(N, H, W);
+        const long long tiles_per_image = (long long)L.nwy * ((W + 63) / 64);
+        if (Hs > 32767 || Ws > 65534 || tiles_per_image * L.pts_per_tile * (long long)sizeof(PtEntry) >= (1ll << 32) ||
+            tiles_per_image * kSegRows * kSegFloats * 4ll >= (1ll << 32))
+            return DS_ERR_UNSUPPORTED;
+    }
     if (stage && (((uintptr_t)workspace & 15) || workspace_bytes < ds_warp_bwd_image_workspace_bytes(N, C, Hs, Ws, H, W)))
         return DS_ERR_WORKSPACE;
     const WarpGeom G = warp_geom(Hs, Ws, H, W);
@@ -1201,7 +1251,7 @@ int ds::warp_bwd_partials(const float* K, const float* Kinv, const float* pose, 
         char* w = (char*)workspace;
         st.hdrA = (int4*)(w + L.off_a);
         st.hdrB = (int4*)(w + L.off_b);
-        st.cb = (int*)(w + L.off_cb);
+        st.hdrC = (int4*)(w + L.off_cb);
         st.seg = (float*)(w + L.off_seg);
         st.pt = (PtEntry*)(w + L.off_pt);
         st.nwy = L.nwy;
