@@ -465,15 +465,13 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
                 float fromL[3], fromR[3];
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
-                    fromL[s] = __shfl_up(kr[s], 1, 64);     // what lane x-1 sends to its right neighbour's column
-                    fromR[s] = __shfl_down(kl[s], 1, 64);   // what lane x+1 sends to its left neighbour's column
-                    if (lane == 0) fromL[s] = 0.f;
-                    if (lane == 63) fromR[s] = 0.f;
+                    fromL[s] = lane_left(kr[s]);    // what lane x-1 sends to its right neighbour's column (lane 0: 0)
+                    fromR[s] = lane_right(kl[s]);   // what lane x+1 sends to its left neighbour's column (lane 63: 0)
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float gc = lane_ok ? g[c] : 0.f;
-                    const float gl = __shfl_up(gc, 1, 64), gr = __shfl_down(gc, 1, 64);
+                    const float gl = lane_left(gc), gr = lane_right(gc);   // DPP wave shifts: one VALU operation each
 #pragma unroll
                     for (int s = 0; s < 3; ++s) win.a[c][s] += fmaf(gr, fromR[s], fmaf(gl, fromL[s], gc * kc[s]));
                     // the outer columns of the window have no owner lane: the two edge lanes keep those sums
@@ -518,9 +516,9 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const float* __restr
                 // against a median of 27 k).  Runs of four lanes or more are summed here first, by a segmented scan over
                 // the lanes -- a fixed tree, so still the same bits every run -- and the run's last lane leaves the four
                 // sums as single values.
-                // (the three shuffles with every lane active: a lane switched off by a short-circuit reads as 0)
-                const bool prev_any = __shfl_up((int)any, 1, 64) != 0;
-                const int prev_y0 = __shfl_up(t.y0, 1, 64), prev_xl = __shfl_up(t.xl, 1, 64);
+                // (the three lane shifts with every lane active: a lane switched off by a short-circuit reads as 0)
+                const bool prev_any = lane_left_i((int)any) != 0;
+                const int prev_y0 = lane_left_i(t.y0), prev_xl = lane_left_i(t.xl);
                 const bool cont = any && lane > 0 && prev_any && prev_y0 == t.y0 && prev_xl == t.xl;
                 const unsigned long long cm = __ballot(cont);
                 const bool scan = __popcll(cm) >= kMinRunLanes - 1;   // uniform: a run of kMinRunLanes may exist
