@@ -202,6 +202,47 @@ def test_image_gradient_any_motion(de, oracle, motion):
     assert np.array_equal(got[0], got[1])
 
 
+def test_image_gradient_fuzz(de, oracle):
+    """Forty seeded cases of the atomic-free image gradient against the oracle's adjoint: odd sizes (widths that are not
+    multiples of 64, two-row images), source dims different from the target's, one to three images, pose scales from
+    sub-pixel to everything out of view, random / smooth / constant depth (constant far planes pile taps onto single
+    texels: the run sums), sparse upstream gradients.  Every case twice: equal bits."""
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for case in range(40):
+        n = int(rng.integers(1, 4))
+        H, W = int(rng.integers(2, 70)), int(rng.integers(2, 200))
+        Hs, Ws = (H, W) if case % 3 else (int(rng.integers(2, 70)), int(rng.integers(2, 200)))
+        K, Kinv = [a.numpy() for a in de.fused.intrinsics(W, H)]
+        src = rng.random((n, 3, Hs, Ws), dtype=np.float32)
+        g_warped = rng.standard_normal((n, 3, H, W)).astype(np.float32)
+        if case % 5 == 4:
+            g_warped *= rng.random((n, 1, H, W)) < 0.1          # mostly zero upstream
+        kind = case % 4
+        depth = (1 + 79 * rng.random((n, H, W), dtype=np.float32) if kind == 0 else
+                 np.broadcast_to(np.linspace(60, 3, H, dtype=np.float32)[None, :, None], (n, H, W)) + rng.random((n, H, W), dtype=np.float32) if kind == 1 else
+                 np.full((n, H, W), 1e6 if kind == 2 else 2.5, dtype=np.float32))
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        scale = [0.003, 0.03, 0.3, 1.5][int(rng.integers(0, 4))]
+        vec = (scale * rng.standard_normal((n, 6)) * np.array([1, 1, 1, 10, 3, 10])).astype(np.float32)
+        pm = oracle.pose_from_vec(vec)
+        got = []
+        for _ in range(2):
+            sr, dep, pose = T(src).requires_grad_(True), T(depth).requires_grad_(True), T(pm).requires_grad_(True)
+            de.ops.warp(T(K), T(Kinv), pose, dep, sr).backward(T(g_warped))
+            got.append((N(sr.grad), N(dep.grad), N(pose.grad)))
+        assert all(np.array_equal(a, b) for a, b in zip(*got)), f"case {case}: two runs differ"
+        gd, gp, gs = zip(*[oracle.warp_bwd(K, Kinv, pm[i], depth[i], src[i], g_warped[i], H, W) for i in range(n)])
+        want = np.stack(gs)
+        if np.abs(want).max() > 0:
+            e = rel_to_max(got[0][0], want)
+            worst = max(worst, e)
+            assert e < 1e-4, f"case {case}: H={H} W={W} Hs={Hs} Ws={Ws} n={n} kind={kind} scale={scale}: {e}"
+        else:
+            assert not got[0][0].any()
+    assert worst > 0
+
+
 @pytest.mark.parametrize("name", LOSS_CASES)
 def test_reference_call_sequence_end_to_end(de, name):
     """train.py:72-92 written against the drop-in modules, gradients through autograd, vs the reference's
