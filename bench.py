@@ -299,8 +299,9 @@ def host_threads():
 
 
 def cpu_baseline(wl, budget_s=8.0):
-    """The CPU oracle (C port, OpenMP over image rows) on whole samples of the same workload, per-sample loop as
-    train.py:39: ~budget_s seconds on all host threads (the reported figure), then ~budget_s / 2 on one thread."""
+    """The CPU oracle (C port) on whole samples of the same workload: ~budget_s seconds on all host threads with OpenMP over
+    image rows inside a sample (per-sample loop as train.py:39), ~budget_s / 2 on one thread, ~budget_s with one sample per
+    thread; the better of the two all-core figures is `value`."""
     import numpy as np
     from oracle import ds_oracle as o
     o.build()
@@ -353,13 +354,41 @@ def cpu_baseline(wl, budget_s=8.0):
         dt = time.perf_counter() - t0
         return n, dt, n * S * H * W / dt / 1e9
 
+    def timed_sample_parallel(threads, budget):
+        """`threads` host threads, each looping whole samples with a one-thread oracle (ctypes drops the GIL in the calls)."""
+        import threading
+        counts, stop = [0] * threads, time.perf_counter() + budget
+
+        def work(i):
+            o.set_threads(1)          # OpenMP's thread count is per calling thread
+            while time.perf_counter() < stop:
+                one_sample()
+                counts[i] += 1
+
+        t0 = time.perf_counter()
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        dt = time.perf_counter() - t0
+        return sum(counts), dt, sum(counts) * S * H * W / dt / 1e9
+
     cores = host_threads()
     n, dt, v = timed(cores, budget_s)
     n1, dt1, v1 = timed(1, budget_s / 2)
-    return dict(value=v, unit="Gpix/s", cores=cores, kind="port", one_thread_value=v1,
-                sample=f"{n} samples (1 target x {S} sources, {H}x{W}, single scale) fwd+bwd in {dt:.1f} s on {cores} "
-                       f"threads (OpenMP over rows, per-sample loop as train.py:39), oracle/ds_oracle.c; {n1} samples in "
-                       f"{dt1:.1f} s on 1 thread; os.cpu_count() = {os.cpu_count()}")
+    ns, dts, vs = timed_sample_parallel(cores, budget_s)
+    how = "OpenMP over rows, per-sample loop as train.py:39"
+    line = dict(value=v, unit="Gpix/s", cores=cores, kind="port", one_thread_value=v1, rows_parallel_value=v,
+                samples_parallel_value=vs)
+    if vs > v:   # the better use of the same cores is the reported baseline
+        line["value"], how = vs, "one sample per thread, one-thread oracle each"
+    line["sample"] = (f"{ns if vs > v else n} samples (1 target x {S} sources, {H}x{W}, single scale) fwd+bwd in "
+                      f"{dts if vs > v else dt:.1f} s on {cores} threads ({how}), oracle/ds_oracle.c; the other split of the cores "
+                      f"({'OpenMP over rows inside a sample' if vs > v else 'one sample per thread'}): "
+                      f"{n if vs > v else ns} samples in {dt if vs > v else dts:.1f} s; {n1} samples in {dt1:.1f} s on 1 thread; "
+                      f"os.cpu_count() = {os.cpu_count()}")
+    return line
 
 
 def free_port():
