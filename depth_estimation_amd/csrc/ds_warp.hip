@@ -191,7 +191,7 @@ constexpr int kBwdRowsSmall = 2;       // for launches too small to fill the chi
 // warp the taps of the 64 pixels of a wave row fall into a window of three source rows x 66 columns that moves down one row
 // per pixel row, so
 //   * lane x owns source column x + cb of the window; the taps of lanes x-1, x, x+1 that fall into that column are
-//     combined in registers (two lane shuffles per value), three running sums per channel (rows r0, r0+1, r0+2);
+//     combined in registers (two DPP lane shifts per value), three running sums per channel (rows r0, r0+1, r0+2);
 //   * a pixel whose taps do not fit the window (a near pixel among far ones: its disparity differs by more than a texel)
 //     is broadcast from its lane and taken over by the two lanes that own its columns if rows and columns are still
 //     inside the window, otherwise it leaves the wave on its own ("point"); if more than a few lanes of a row misfit (strong
@@ -206,12 +206,12 @@ constexpr int kBwdRowsSmall = 2;       // for launches too small to fill the chi
 //     two rows above the first row the wave finishes, kSegRows slots; the tile's record keeps rbase, a mask of the filled
 //     slots and each slot's first column.  A row that does not fit (the window jumped backwards or far ahead, or comes to a
 //     slot a second time) leaves as points;
-//   * a point (2 texels x 3 channels of one source row) is appended to the tile's point list, its position from a ballot
-//     prefix inside the wave; the record keeps the count and the row / column range of the list.
-// img_reduce_kernel then forms every texel of g_src exactly once -- one thread per texel column of one source row: it looks
-// through the tile records of its image for segments of its row that cover its columns and for point lists whose ranges
-// include them, and adds what it finds IN A FIXED ORDER (tiles by index, a tile's points in list order), so the sum is
-// bit-identical from run to run; the texel is written with a plain store (g_src needs no clearing).  First version of the
+//   * a point (one pixel's tap: PtEntry) is appended to the tile's point list, its position from a ballot prefix inside
+//     the wave; the record keeps the count and the row / column range of the list.
+// img_reduce_kernel then forms every texel of g_src exactly once -- one thread per texel column of a source row: it looks
+// through the tile records of its image for segments of its rows that cover its columns and for point lists whose ranges
+// include them, and adds what it finds IN AN ORDER THAT DEPENDS ON THE DATA ONLY (segments by tile index; a list's entries
+// batch by batch, inside a batch by the integer bidding described there), so the sum is bit-identical from run to run; the texel is written with a plain store (g_src needs no clearing).  First version of the
 // round: per-row directories filled through returning integer atomics and a 64-bit fixed-point sum in the reducer -- correct
 // and repeatable, and 4x slower than the float atomics (the atomics' round trips serialise the row loop, the fixed-point
 // conversions cost 128 us): profiles/r03_kb2_image_gradient.txt.
@@ -221,15 +221,15 @@ constexpr int kSegFloats = 3 * 66;  // one slot: 3 channels x (outer column, 64 
 // 16-byte words (as an array of 112-byte structs every lane touched a cache line of its own: 47 of the reducer's 85 us):
 //   hdrA[tile] = { rbase: source row of slot 0,  mask: filled slots (bit 31: the point list is not empty),
 //                  cbmin, cbmax: range of cb[] over the filled slots }
-//   hdrB[tile] = { npt: entries of the point list,  prmin, prmax: the rows they span,  - }
+//   hdrB[tile] = { npt: entries of the point list,  prmin, prmax: the rows they span,
+//                  (min + 1) << 16 | (max + 1) of the columns their taps start in }
 //   hdrC[tile] = 16 signed bytes: [k] = slot k's window offset cb (its first OWNED column, entry 1 of its 66, is source
 //                  column 64 * bx + cb; a window further than 127 columns from its pixels gets no slot)
-//   (round 3 first had cb[tile][18] ints read by dependent loads: [k] = column of slot k, [16], [17] = the range of
-//                  the points' left columns
+//   (first these were ints in an array of their own, read by dependent loads after the records: 129 -> 117 us)
 // A point = one pixel's whole bilinear tap, 24 bytes: the reducer forms the four weights from the two fractions exactly as
 // make_tap does (sy * ex, sy * wx, ny * ex, ny * wx with ex = 1 - wx, sy = 1 - ny) and the 12 products g[c] * w itself, so the
-// sums get the bits they had when pass 1 formed the products (32 bytes per texel ROW, two entries per pixel: 189 MB of
-// stores per launch with bench.py's per-pixel random depth, 39 of pass 1's 69 us).  A tap on the last column has
+// sums get the bits they would have if pass 1 formed the products (first: 32 bytes per texel ROW, two entries per pixel;
+// the change moved no time -- the reducer is latency, not bytes).  A tap on the last column has
 // (wx, col) = (1, Ws-2) instead of make_tap's shifted pair: the same texels and products.  A single value for one texel
 // (a window row without a slot, the sum of a run) is the entry (value, wx = 0, ny = 0): weight 1 on (row, col), 0 elsewhere.
 struct PtEntry {

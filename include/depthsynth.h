@@ -75,9 +75,10 @@ int ds_warp_fwd(const float* K, const float* Kinv, const float* pose, const floa
 size_t ds_warp_bwd_workspace_bytes(int N, int H, int W);
 /* workspace of ds_warp_bwd WITH the source-image gradient (g_src != NULL): for C == 3 the pose partials plus the staging of
  * the scatter -- per wave of the launch (64 columns x 8 rows of pixels) a record, 16 row slots of 66 x 3 floats and a point
- * list: about 140 bytes per warped pixel, sized for the worst case (every pixel leaving its wave on its own); only what a
- * warp actually stages is touched (~16 bytes per pixel for a smooth warp).  16-byte aligned, need not be initialised.
- * Other C: = ds_warp_bwd_workspace_bytes. */
+ * list: about 113 bytes per warped pixel (333 MB for 24 warps of 192 x 640), sized for the worst case (every finished
+ * window row without a slot); only what a warp actually stages is touched (~16 bytes per pixel for a smooth warp, 24 when
+ * every pixel leaves its wave on its own).  16-byte aligned, need not be initialised.  Other C: = ds_warp_bwd_workspace_bytes.
+ * Limits of the C == 3 path: Hs <= 32767, Ws <= 65534 (DS_ERR_UNSUPPORTED beyond). */
 size_t ds_warp_bwd_image_workspace_bytes(int N, int C, int Hs, int Ws, int H, int W);
 
 /* autograd of ds_warp_fwd: g_depth (N,H,W), g_pose (N,3,4) (deterministic two-stage reduction, no atomics), g_src
