@@ -520,6 +520,9 @@ def main():
                     help="pyramid workloads: all levels one after the other on the main stream (default: coarse levels forked "
                          "onto side streams and joined inside every step)")
     ap.add_argument("--dry", action="store_true", help="launcher / rendezvous check on the CPU (gloo), no kernels")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 with every rank on cuda:0 and gloo instead of RCCL (which refuses two ranks on one device): the "
+                         "whole multi-rank code path with real kernels on a one-GPU box; the line says so and is not a scaling figure")
     ap.add_argument("--no-also", action="store_true",
                     help="default workload at N=1: skip the short joined runs of the other workloads (the `also` object)")
     args = ap.parse_args()
@@ -543,13 +546,18 @@ def main():
         return full_step.main(args, rank, local_rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import depth_estimation_amd as de
     wl = WORKLOADS[args.workload]
@@ -775,6 +783,8 @@ def main():
             line["ms_per_step_no_spin_up"] = round(no_spin / args.steps * 1e3, 5)
         if group is not None:
             line["process_group"] = group
+        if args.rehearse_on_one_gpu:
+            line["rehearsal"] = "all ranks share cuda:0, gloo instead of RCCL: checks the multi-rank path, not a scaling figure"
         if levels_one_stream is not None:
             line["levels_on_one_stream"] = levels_one_stream
         if pipelined is not None:
