@@ -520,147 +520,6 @@ __global__ __launch_bounds__(64 * kFwdWaves, 4) void warp_idt_kernel(WarpIdtPara
     }
 }
 
-// =====================================================================================================
-// forward, register-lean variant for many groups (S = 4 with the identity groups, G = 8): three raw rows per plane in
-// registers, neighbours through DPP wave shifts folded into the adds, 62 useful columns per wave.  Same arithmetic,
-// same results; ~25 % slower per pixel than the LDS-exchange kernel above, but 3 registers per plane instead of 7.
-// =====================================================================================================
-template <int S, bool IDT>
-struct FwdState {
-    static constexpr int G = IDT ? 2 * S : S;
-    float X[G][3][3];  // [group][channel][slot]; products are re-formed per window (registers > 6 % VALU)
-    float Y[3][3];
-};
-
-template <int S, bool IDT, int SLOT>
-__device__ __forceinline__ void fwd_place(FwdState<S, IDT>& st, const float (&nx)[FwdState<S, IDT>::G][3],
-                                          const float (&ny)[3]) {
-    constexpr int G = FwdState<S, IDT>::G;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        st.Y[c][SLOT] = ny[c];
-#pragma unroll
-        for (int g = 0; g < G; ++g) st.X[g][c][SLOT] = nx[g][c];
-    }
-}
-
-// photometric error of the window centred on row MID for every group; E[g] = ((e0+e1)+e2)/3
-template <int S, bool IDT, int T, int M, int Bt>
-__device__ __forceinline__ void fwd_window(FwdState<S, IDT>& st, float (&E)[FwdState<S, IDT>::G]) {
-    constexpr int G = FwdState<S, IDT>::G;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float ay, ayy;
-        win_target(st.Y[c][T], st.Y[c][M], st.Y[c][Bt], ay, ayy);
-        TgtStats ts;
-        target_stats(ay, ayy, ts);
-        const float yc = st.Y[c][M];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float ax, axx, axy;
-            win_pair(st.X[g][c][T], st.X[g][c][M], st.X[g][c][Bt], st.Y[c][T], st.Y[c][M], st.Y[c][Bt], ax, axx, axy);
-            SsimOut so;
-            ssim_from_sums(ax, axx, axy, ts, so);
-            const float e = 0.85f * clamp01(so.v) + 0.15f * fabsf(yc - st.X[g][c][M]);
-            E[g] = (c == 0) ? e : E[g] + e;
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) E[g] = div3(E[g]);
-}
-
-template <int S, bool IDT>
-__global__ __launch_bounds__(64 * kWaves) void photo_fwd_dpp_kernel(PhotoFwdParams P) {
-    constexpr int G = FwdState<S, IDT>::G;
-    const BandGeom g = band_geom<1>(P.B, P.H, P.W, P.nbx, P.nby, P.RB);
-    if (!g.active) return;
-    const unsigned cl = (unsigned)g.cl * 4u;  // lane's column byte offset: the only per-lane part of a load address
-    const int H = P.H, W = P.W;
-    const size_t HW = (size_t)H * W;
-    const rsrc_t tp = make_rsrc(P.target + (size_t)g.b * P.tgt_stride_b);
-    const rsrc_t pp = make_rsrc(P.preds + (size_t)g.b * P.pred_stride_b);
-    const rsrc_t sp = make_rsrc(IDT ? P.src + (size_t)g.b * (S * 3 * HW) : P.preds);
-    const unsigned uHW = (unsigned)HW;
-    const bool lane_out = g.lane >= 1 && g.lane <= 62 && g.col < W;
-
-    FwdState<S, IDT> st;
-    float nx[G][3], ny[3];
-    auto load_row = [&](int r) {
-        const unsigned ro = (unsigned)(reflect_idx(r, H) * W);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            ny[c] = buf_load_f32(tp, cl, c * uHW + ro);
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                nx[s][c] = buf_load_f32(pp, cl, (s * 3 + c) * uHW + ro);
-                if (IDT) nx[S + s][c] = buf_load_f32(sp, cl, (s * 3 + c) * uHW + ro);
-            }
-        }
-    };
-    float sum_ratio = 0.f, sum_out = 0.f;
-    auto emit = [&](int y, const float (&E)[G]) {
-        float best = E[0];
-        int bi = 0;
-#pragma unroll
-        for (int s = 1; s < S; ++s)
-            if (E[s] < best) { best = E[s]; bi = s; }
-        const size_t o = (size_t)g.b * HW + (size_t)y * W + g.col;
-        if (lane_out) {
-            const unsigned a = (unsigned)(bi + P.s_offset);
-            bool keep = true;
-            if (P.s_offset > 0) keep = best < P.out[o];  // later chunk: strictly smaller wins (first index on ties)
-            if (keep) {
-                P.out[o] = best;
-                if (P.aux) P.aux[o] = (uint8_t)a;
-            }
-            if (IDT) {
-                float bid = E[S];
-#pragma unroll
-                for (int s = 1; s < S; ++s) bid = fminf(bid, E[S + s]);
-                P.idt[o] = bid;
-                sum_ratio += best / expf(bid + 1e-6f);  // train.py:88
-                sum_out += best;                        // train.py:92
-            }
-        }
-    };
-
-    // prologue: rows y0-1, y0 into slots 0,1; steady state handles row r in slot (r-(y0-1))%3
-    load_row(g.y0 - 1);
-    fwd_place<S, IDT, 0>(st, nx, ny);
-    load_row(g.y0);
-    fwd_place<S, IDT, 1>(st, nx, ny);
-    // the next row is always prefetched, also past the chunk's end (indices are clamped, the values unused): a
-    // conditional load would make the compiler drain vmcnt to 0 right behind it
-    load_row(g.y0 + 1);
-    float E[G];
-    for (int y = g.y0; y < g.yend; y += 3) {
-        // output row y: rows (y-1,y,y+1) in slots (0,1,2)
-        fwd_place<S, IDT, 2>(st, nx, ny);
-        load_row(y + 2);
-        fwd_window<S, IDT, 0, 1, 2>(st, E);
-        emit(y, E);
-        if (y + 1 >= g.yend) break;
-        fwd_place<S, IDT, 0>(st, nx, ny);
-        load_row(y + 3);
-        fwd_window<S, IDT, 1, 2, 0>(st, E);
-        emit(y + 1, E);
-        if (y + 2 >= g.yend) break;
-        fwd_place<S, IDT, 1>(st, nx, ny);
-        load_row(y + 4);
-        fwd_window<S, IDT, 2, 0, 1>(st, E);
-        emit(y + 2, E);
-    }
-    if (IDT) {
-        sum_ratio = wave_sum(sum_ratio);
-        sum_out = wave_sum(sum_out);
-        if (g.lane == 0) {
-            const int wg = xcd_remap(blockIdx.x, gridDim.x) * kWaves + (threadIdx.x >> 6);
-            P.wave_partials[2 * wg + 0] = sum_ratio;
-            P.wave_partials[2 * wg + 1] = sum_out;
-        }
-    }
-}
-
 // per-image sums of the wave partials, fixed order, double accumulation -> means (B,2)
 __global__ void loss_finalize_kernel(const float* __restrict__ wave_partials, int waves_per_image, double inv_hw,
                                      float* __restrict__ sums) {
@@ -1557,7 +1416,8 @@ inline Geom make_geom(int B, int H, int W, int halo, int useful, double halo_row
 
 // Forward loss kernels.  The channel-split LDS-exchange kernel (one 4-wave workgroup per band of 64 columns and row
 // chunk) is used wherever a wave's partial sums fit the register file without spilling (G = groups per launch <= 6:
-// 111 VGPRs at G = 4, 154 at G = 6), the DPP kernel (one wave per band of 62 useful columns) for G = 8.
+// 111 VGPRs at G = 4, 154 at G = 6); G = 8 (S = 4 with the identity groups) runs as two four-group launches
+// (fused_loss_fwd_partials).
 inline bool fwd_uses_lds(int S, bool idt) { return (idt ? 2 * S : S) <= 6; }
 
 // Row chunking of the channel-split kernel: one workgroup per (band, row chunk); a CU holds four of them (VGPR
@@ -1611,7 +1471,7 @@ inline Geom make_fwd_lds_geom(int B, int H, int W, int groups, int per_cu_given 
     return g;
 }
 inline Geom make_fwd_geom(int B, int H, int W, int S, bool idt) {
-    return fwd_uses_lds(S, idt) ? make_fwd_lds_geom(B, H, W, idt ? 2 * S : S) : make_geom(B, H, W, 1, 62, 1.0);
+    return make_fwd_lds_geom(B, H, W, idt && fwd_uses_lds(S, true) ? 2 * S : S);   // (S = 4 with identity groups: two S-group launches)
 }
 
 inline bool bad_dims(int B, int S, int H, int W) {
@@ -1641,7 +1501,7 @@ int launch_photo_fwd(int S, PhotoFwdParams P, Geom* geom_out, hipStream_t st) {
             case 6: hipLaunchKernelGGL((photo_fwd_kernel<3, true>), g, b, 0, st, P); break;
         }
     } else {
-        hipLaunchKernelGGL((photo_fwd_dpp_kernel<4, true>), g, b, 0, st, P);  // S = 4 with identity groups only
+        return DS_ERR_UNSUPPORTED;   // more than six groups (S = 4 with the identity groups): two launches, fused_loss_fwd_partials
     }
     DS_CHECK_LAUNCH();
     return DS_OK;
@@ -1766,8 +1626,7 @@ size_t ds_fused_loss_workspace_bytes(int B, int H, int W) {
     // enough for every forward kernel variant (the entry point has no S)
     size_t n = 0;
     for (int S = 1; S <= DS_MAX_SOURCES; ++S) {
-        const Geom g = make_fwd_geom(B, H, W, S, true);
-        const size_t k = fwd_uses_lds(S, true) ? (size_t)g.nwaves : (size_t)g.nblocks * kWaves;
+        const size_t k = (size_t)make_fwd_geom(B, H, W, S, true).nwaves;
         if (k > n) n = k;
         const size_t k2 = (size_t)make_fwd_geom(B, H, W, S, false).nwaves;   // identity map given (photo_fwd_idm_kernel)
         if (k2 > n) n = k2;
@@ -1979,6 +1838,17 @@ int ds::fused_loss_fwd_partials(const float* warped, const float* src, const flo
     P.B = B; P.H = H; P.W = W;
     P.out = out_loss; P.idt = idt_loss; P.aux = aux; P.wave_partials = (float*)workspace;
     Geom g;
+    if (!fwd_uses_lds(S, true)) {
+        // S = 4: eight groups do not fit one workgroup's registers and LDS.  The identity map first (the un-warped sources as
+        // the "predictions" of a four-group launch, min over them -> idt_loss), then the warped groups against it -- the
+        // same arithmetic in two launches.  (Rounds 1-2 had a register-lean DPP kernel for this case alone, 25 % slower per
+        // pixel; the reference never runs S = 4, constants.py:6.)
+        P.preds = src; P.src = nullptr; P.out = idt_loss; P.idt = nullptr; P.aux = nullptr; P.wave_partials = nullptr;
+        int rc = launch_photo_fwd<false>(S, P, &g, stream);
+        if (rc != DS_OK) return rc;
+        return fused_loss_fwd_idm_partials(warped, target, idt_loss, B, S, H, W, out_loss, aux, workspace, workspace_bytes,
+                                           waves_per_image, stream);
+    }
     int rc = launch_photo_fwd<true>(S, P, &g, stream);
     if (rc != DS_OK) return rc;
     *waves_per_image = g.nbx * g.nby;
